@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fp64 CSR SpMV with fused shift (y = sigma*x - H x), the kernel that
+dominates the inexact-Lanczos shift-and-invert inner loop, at BASELINE.json's metric
+configuration (random-sparse Hermitian, N = 1e7, nnz/row ~ 64), plus Lanczos iterations/s
+on the same operator.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  With N > 1 the SAME N = 1e7 operator is row-partitioned over the ranks
+(strong scaling: total work fixed); every step is an RCCL all-gather of the operand slice
+followed by the local CSR sweep.  A "step" is one operator application.  Inputs are
+generated on the device and are resident in HBM before the timed region.
+
+Rank 0 prints ONE JSON line; `value` is whole-job algorithmic GB/s (SURVEY.md section 8d
+bytes of the GLOBAL operator x steps / max-over-ranks wall time); `roofline` prices the
+dominant kernel per GPU against the 8 TB/s HBM peak with HIP events recorded on the
+library's own stream; `cpu_baseline` times the same product through scipy's csr_matvec
+(the routine the reference's `H @ x` reaches) on a bounded row slab of the same operator.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--nnz-row", type=int, default=64)
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--sigma", type=float, default=0.02)
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 CSR-vector, 2 CSR-stream")
+    ap.add_argument("--no-lanczos", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--lanczos-L", type=int, default=3)
+    return ap.parse_args()
+
+
+def global_bytes(N, nnz):
+    return nnz * 12 + (N + 1) * 4 + 8 * N + 8 * N
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import eigensolvers_amd as ea
+    from eigensolvers_amd import distributed as D
+
+    rank, world, local_rank = D.world_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dist = None
+    if world > 1:
+        dist = D.init_process_group_gloo()
+    ctx = ea.HipContext(local_rank)
+    ea.HipContext._default = ctx
+    if world > 1:
+        D.attach_rccl(ctx)
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def allmax(x):
+        if dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def allsum(x):
+        if dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t[0])
+
+    N = a.n
+    b, e = D.row_range(N, world, rank)
+    t_gen = time.time()
+    H = ea.HipCsrOperator.generate(N, a.nnz_row, seed=a.seed, row_begin=b, row_end=e, ctx=ctx)
+    if a.variant:
+        H.set_variant(a.variant)
+    barrier()
+    t_gen = time.time() - t_gen
+    nnz_total = int(allsum(float(H.nnz)))
+    x = ea.HipVector(np.random.default_rng(100 + rank).standard_normal(e - b), ctx=ctx)
+    y = ctx.alloc(e - b)
+
+    for _ in range(a.warmup):
+        H.apply_shifted(a.sigma, x._buf, y)
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(a.steps):
+        H.apply_shifted(a.sigma, x._buf, y)
+    dev_ms = ctx.timer_stop()              # HIP events on the stream the kernels run on
+    barrier()
+    wall = allmax(time.perf_counter() - t0)
+    dev_ms = allmax(dev_ms)
+
+    gbytes = global_bytes(N, nnz_total) / 1e9
+    value = gbytes * a.steps / wall
+    per_gpu_bytes = H.algorithmic_bytes() / 1e9          # local rows, x counted once (full length)
+    achieved = per_gpu_bytes / (dev_ms / a.steps / 1e3)
+    out = {
+        "metric": "fp64 CSR SpMV GB/s (fused shift y = sigma*x - H x)", "value": round(value, 2), "unit": "GB/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(wall / a.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"random-sparse Hermitian CSR N={N} nnz/row~{a.nnz_row} (BASELINE metric config), "
+                               f"row-partitioned over {world} GPU(s)",
+                   "N": N, "nnz": nnz_total, "nnz_per_row": round(nnz_total / N, 3), "sigma": a.sigma,
+                   "kernel_variant": {0: "auto(csr-stream)", 1: "csr-vector", 2: "csr-stream"}[a.variant],
+                   "generator_seed": a.seed, "generate_s": round(t_gen, 2)},
+        "roofline": {"bound": "hbm", "kernel": "spmv_stream_kernel" if a.variant != 1 else "spmv_vector_kernel",
+                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": int(H.algorithmic_bytes()),
+                     "avg_launch_ms": round(dev_ms / a.steps, 5)},
+    }
+
+    # ---- Lanczos iterations/s on the same operator (outside the timed SpMV region) ----
+    if not a.no_lanczos:
+        opts = {"linearSystemArgs": {"linearSolver": "minres", "linearIter": 2000, "linear_tol": 1e-10}}
+        from eigensolvers_amd.generators import guess_vector
+        v0 = ea.HipVector(guess_vector(N, 1, b, e).copy(), opts, ctx=ctx)
+        barrier()
+        tl = time.perf_counter()
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):          # keep stdout to the single JSON line
+            ev, Y, st = ea.inexactLanczosDiagonalization(H, v0, a.sigma, a.lanczos_L, 1, 1e-12, writeOut=False)
+        barrier()
+        tl = allmax(time.perf_counter() - tl)
+        res = ea.true_residual_norms(H, ev, Y, 1)
+        inner = v0.last_solve_stats["iterations"] if v0.last_solve_stats else None
+        out["lanczos"] = {"cum_iters": st["cumIter"], "seconds": round(tl, 3),
+                          "iters_per_s": round(st["cumIter"] / tl, 4), "ritz_value": float(ev[0]),
+                          "true_residual_norm": float(res[0]), "minres_iters_first_solve": inner,
+                          "L": a.lanczos_L, "linear_tol": 1e-10}
+
+    # ---- CPU baseline: scipy csr_matvec on a bounded row slab (rank 0, single GPU only) ----
+    if rank == 0 and world == 1 and not a.no_cpu:
+        rows = min(N, max(1000, int(2.0e7 // max(a.nnz_row, 1))))     # ~2e7 non-zeros
+        slab = ea.HipCsrOperator.generate(N, a.nnz_row, seed=a.seed, row_begin=0, row_end=rows, ctx=ctx).to_scipy()
+        xh = np.random.default_rng(100).standard_normal(N)
+        slab @ xh
+        reps, tc = 0, time.perf_counter()
+        while reps < 200 and time.perf_counter() - tc < 12.0:
+            yh = a.sigma * xh[:rows] - slab @ xh
+            reps += 1
+        tc = time.perf_counter() - tc
+        sb = (slab.nnz * 12 + (rows + 1) * 4 + 8 * N + 8 * rows) / 1e9
+        try:
+            import threadpoolctl
+            blas = [(d.get("internal_api"), d.get("num_threads")) for d in threadpoolctl.threadpool_info()]
+        except Exception:
+            blas = None
+        out["cpu_baseline"] = {"value": round(sb * reps / tc, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+                               "sample": f"rows [0,{rows}) of the same operator ({slab.nnz} nnz), x of full length {N}, "
+                                         f"{reps} reps of sigma*x - H@x via scipy.sparse csr_matvec (single-threaded), "
+                                         f"{tc:.1f} s",
+                               "host_cpus": os.cpu_count(), "blas_threads": blas,
+                               "numpy": np.__version__, "scipy": __import__("scipy").__version__}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

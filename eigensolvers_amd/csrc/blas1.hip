@@ -1,0 +1,410 @@
+// BLAS-1 class and tall-skinny kernels of the Krylov loop (all HBM-bound, fp64).
+//
+// Every kernel is a grid-stride sweep with 16-byte (double2) accesses, at most
+// HIPEIG_MAX_PARTIALS workgroups of 256 threads.  Reductions are two-stage with a fixed
+// tree (wave shuffle -> LDS -> per-workgroup partial -> fixed-order final sum), never
+// atomics, so results are bitwise reproducible.
+#include "common.h"
+#include <math.h>
+
+struct PtrTable {
+  const double* p[HIPEIG_MAX_COLS];
+};
+struct CoefTable {
+  double c[HIPEIG_MAX_COLS];
+};
+
+// ---- stage-2 reduction: out[j] = sum_b partials[b*ncols + j] ---------------------------
+__global__ void finalize_kernel(const double* __restrict__ partials, int nblocks, int ncols,
+                                double* __restrict__ out) {
+  __shared__ double lds[4];
+  const int j = blockIdx.x;
+  double a = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) a += partials[(size_t)b * ncols + j];
+  a = block_reduce_sum(a, lds);
+  if (threadIdx.x == 0) out[j] = a;
+}
+
+static int finalize_to_host(hipeig_ctx* c, int nblocks, int ncols, double* host_out) {
+  hipLaunchKernelGGL(finalize_kernel, dim3(ncols), dim3(HIPEIG_BLOCK), 0, c->stream,
+                     c->d_partials, nblocks, ncols, c->d_scalars);
+  HIPEIG_CHECK(hipGetLastError());
+  if (hipeig_allreduce_sum(c, c->d_scalars, ncols)) return 4;
+  if (host_out) {
+    HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(double) * ncols,
+                                hipMemcpyDeviceToHost, c->stream));
+    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(host_out, c->h_scalars, sizeof(double) * ncols);
+  }
+  return 0;
+}
+
+// ---- dot / nrm2 ------------------------------------------------------------------------
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+dot_kernel(int64_t n, const double* __restrict__ x, const double* __restrict__ y,
+           double* __restrict__ partials) {
+  __shared__ double lds[4];
+  const int64_t n2 = n >> 1;
+  const double2* x2 = reinterpret_cast<const double2*>(x);
+  const double2* y2 = reinterpret_cast<const double2*>(y);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double a0 = 0.0, a1 = 0.0;
+  for (; i + stride < n2; i += 2 * stride) {        // two independent 16-byte loads in flight
+    const double2 xa = x2[i], ya = y2[i];
+    const double2 xb = x2[i + stride], yb = y2[i + stride];
+    a0 = fma(xa.x, ya.x, a0); a0 = fma(xa.y, ya.y, a0);
+    a1 = fma(xb.x, yb.x, a1); a1 = fma(xb.y, yb.y, a1);
+  }
+  for (; i < n2; i += stride) {
+    const double2 xa = x2[i], ya = y2[i];
+    a0 = fma(xa.x, ya.x, a0); a0 = fma(xa.y, ya.y, a0);
+  }
+  double a = a0 + a1;
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) a = fma(x[n - 1], y[n - 1], a);
+  a = block_reduce_sum(a, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = a;
+}
+
+extern "C" int hipeig_dot(hipeig_ctx* c, int64_t n, const double* x, const double* y, double* out) {
+  HIPEIG_REQUIRE(out != nullptr, "null output");
+  const int g = grid_for(n, 8);
+  hipLaunchKernelGGL(dot_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, x, y, c->d_partials);
+  HIPEIG_CHECK(hipGetLastError());
+  return finalize_to_host(c, g, 1, out);
+}
+
+extern "C" int hipeig_nrm2(hipeig_ctx* c, int64_t n, const double* x, double* out) {
+  double ss = 0.0;
+  int rc = hipeig_dot(c, n, x, x, &ss);
+  if (rc) return rc;
+  *out = sqrt(ss);
+  return 0;
+}
+
+// ---- scale / axpby ---------------------------------------------------------------------
+// y = x * alpha (divide == 0) or y = x / alpha (divide == 1; the reference divides, e.g.
+// array /= norm at numpyVector.py:77 and x/np.sqrt(innerprod) at :142)
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+scale_kernel(int64_t n, double alpha, int divide, const double* __restrict__ x, double* __restrict__ y) {
+  const int64_t n2 = n >> 1;
+  const double2* x2 = reinterpret_cast<const double2*>(x);
+  double2* y2 = reinterpret_cast<double2*>(y);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (divide) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+      double2 v = x2[i];
+      v.x /= alpha; v.y /= alpha;
+      y2[i] = v;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = x[n - 1] / alpha;
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+      double2 v = x2[i];
+      v.x *= alpha; v.y *= alpha;
+      y2[i] = v;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = x[n - 1] * alpha;
+  }
+}
+
+extern "C" int hipeig_scale(hipeig_ctx* c, int64_t n, double alpha, const double* x, double* y) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 4)), dim3(HIPEIG_BLOCK), 0, c->stream, n, alpha, 0, x, y);
+  HIPEIG_CHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hipeig_divide(hipeig_ctx* c, int64_t n, double alpha, const double* x, double* y) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 4)), dim3(HIPEIG_BLOCK), 0, c->stream, n, alpha, 1, x, y);
+  HIPEIG_CHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hipeig_normalize(hipeig_ctx* c, int64_t n, double* x, double* norm_out) {
+  double nrm = 0.0;
+  int rc = hipeig_nrm2(c, n, x, &nrm);
+  if (rc) return rc;
+  if (norm_out) *norm_out = nrm;
+  // la.norm then array /= norm (numpyVector.py:76-78): a true division, not a
+  // multiplication by the reciprocal, to stay on the reference's rounding.
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 4)), dim3(HIPEIG_BLOCK), 0, c->stream, n, nrm, 1, x, x);
+  HIPEIG_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+axpby_kernel(int64_t n, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
+  const int64_t n2 = n >> 1;
+  const double2* x2 = reinterpret_cast<const double2*>(x);
+  double2* y2 = reinterpret_cast<double2*>(y);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    const double2 xv = x2[i];
+    double2 yv = y2[i];
+    yv.x = a * xv.x + b * yv.x;
+    yv.y = a * xv.y + b * yv.y;
+    y2[i] = yv;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = a * x[n - 1] + b * y[n - 1];
+}
+
+extern "C" int hipeig_axpby(hipeig_ctx* c, int64_t n, double a, const double* x, double b, double* y) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 4)), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, x, b, y);
+  HIPEIG_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- linear combination: out = (accumulate ? out : 0) + sum_j c[j]*v_j -----------------
+template <int MB>
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+lincomb_kernel(int64_t n, int m, PtrTable tab, CoefTable cf, const double* __restrict__ dcoef,
+               double dscale, int accumulate, double* __restrict__ out) {
+  double cj[MB];
+#pragma unroll
+  for (int j = 0; j < MB; ++j) cj[j] = (j < m) ? (dcoef ? dscale * dcoef[j] : cf.c[j]) : 0.0;
+  const int64_t n2 = n >> 1;
+  double2* o2 = reinterpret_cast<double2*>(out);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    double2 acc = accumulate ? o2[i] : make_double2(0.0, 0.0);
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      if (j < m) {
+        const double2 v = reinterpret_cast<const double2*>(tab.p[j])[i];
+        acc.x = fma(cj[j], v.x, acc.x);
+        acc.y = fma(cj[j], v.y, acc.y);
+      }
+    }
+    o2[i] = acc;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    double acc = accumulate ? out[n - 1] : 0.0;
+    for (int j = 0; j < m; ++j) acc = fma(cj[j], tab.p[j][n - 1], acc);
+    out[n - 1] = acc;
+  }
+}
+
+// dcoef (device, scaled by dscale) overrides coeffs (host) when non-null; it holds k doubles.
+static int lincomb_impl(hipeig_ctx* c, int64_t n, int k, const double* coeffs, const double* dcoef,
+                        double dscale, const double* const* vecs, double* out, int accumulate_first) {
+  if (n == 0) return 0;
+  const int g = grid_for(n, 2);
+  for (int j0 = 0; j0 < k; j0 += HIPEIG_MAX_COLS) {
+    const int m = (k - j0 < HIPEIG_MAX_COLS) ? (k - j0) : HIPEIG_MAX_COLS;
+    PtrTable tab;
+    CoefTable cf;
+    for (int j = 0; j < HIPEIG_MAX_COLS; ++j) {
+      tab.p[j] = (j < m) ? vecs[j0 + j] : nullptr;
+      cf.c[j] = (j < m && coeffs) ? coeffs[j0 + j] : 0.0;
+    }
+    const int acc = (j0 > 0) || accumulate_first;
+    const double* dc = dcoef ? dcoef + j0 : nullptr;
+    if (m <= 4)
+      hipLaunchKernelGGL((lincomb_kernel<4>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, m, tab, cf, dc, dscale, acc, out);
+    else if (m <= 8)
+      hipLaunchKernelGGL((lincomb_kernel<8>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, m, tab, cf, dc, dscale, acc, out);
+    else
+      hipLaunchKernelGGL((lincomb_kernel<HIPEIG_MAX_COLS>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, m, tab, cf, dc, dscale, acc, out);
+    HIPEIG_CHECK(hipGetLastError());
+  }
+  return 0;
+}
+
+extern "C" int hipeig_lincomb(hipeig_ctx* c, int64_t n, int k, const double* coeffs,
+                              const double* const* vecs, double* out) {
+  HIPEIG_REQUIRE(k >= 1, "need at least one vector");
+  for (int j = 0; j < k; ++j) HIPEIG_REQUIRE(vecs[j] != out, "out must not alias an input");
+  return lincomb_impl(c, n, k, coeffs, nullptr, 1.0, vecs, out, 0);
+}
+
+extern "C" int hipeig_lincomb_block(hipeig_ctx* c, int64_t n, int m, int k, const double* C, int ldc,
+                                    const double* const* vecs, double* const* outs) {
+  HIPEIG_REQUIRE(m >= 1 && k >= 1 && ldc >= k, "bad shape");
+  double* col = (double*)malloc(sizeof(double) * m);
+  HIPEIG_REQUIRE(col != nullptr, "out of host memory");
+  int rc = 0;
+  for (int cidx = 0; cidx < k && !rc; ++cidx) {
+    for (int j = 0; j < m; ++j) col[j] = C[(size_t)j * ldc + cidx];
+    rc = lincomb_impl(c, n, m, col, nullptr, 1.0, vecs, outs[cidx], 0);
+  }
+  free(col);
+  return rc;
+}
+
+extern "C" int hipeig_multi_axpy(hipeig_ctx* c, int64_t n, int m, const double* const* Y,
+                                 const double* coef, double* x) {
+  if (m == 0) return 0;
+  return lincomb_impl(c, n, m, coef, nullptr, 1.0, Y, x, 1);
+}
+
+// ---- multi_dot: out[j] = <Y_j, x> -------------------------------------------------------
+template <int MB>
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+multi_dot_kernel(int64_t n, int m, PtrTable tab, const double* __restrict__ x,
+                 double* __restrict__ partials, int pstride) {
+  __shared__ double lds[4 * MB];
+  double acc[MB];
+#pragma unroll
+  for (int j = 0; j < MB; ++j) acc[j] = 0.0;
+  const int64_t n2 = n >> 1;
+  const double2* x2 = reinterpret_cast<const double2*>(x);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    const double2 xv = x2[i];
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      if (j < m) {
+        const double2 v = reinterpret_cast<const double2*>(tab.p[j])[i];
+        acc[j] = fma(v.x, xv.x, acc[j]);
+        acc[j] = fma(v.y, xv.y, acc[j]);
+      }
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < MB; ++j)
+      if (j < m) acc[j] = fma(tab.p[j][n - 1], x[n - 1], acc[j]);
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < MB; ++j) {
+    const double r = wave_reduce_sum(acc[j]);
+    if (lane == 0) lds[wid * MB + j] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < m) {
+    const int j = threadIdx.x;
+    partials[(size_t)blockIdx.x * pstride + j] = lds[j] + lds[MB + j] + lds[2 * MB + j] + lds[3 * MB + j];
+  }
+}
+
+// partials laid out [block][pstride]; columns j0..j0+m of this launch go to offset j0.
+static int multi_dot_launch(hipeig_ctx* c, int64_t n, int m, const double* const* Y, const double* x,
+                            int g, int pstride, int poff) {
+  PtrTable tab;
+  for (int j = 0; j < HIPEIG_MAX_COLS; ++j) tab.p[j] = (j < m) ? Y[j] : nullptr;
+  double* part = c->d_partials + poff;
+  if (m <= 4)
+    hipLaunchKernelGGL((multi_dot_kernel<4>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, m, tab, x, part, pstride);
+  else if (m <= 8)
+    hipLaunchKernelGGL((multi_dot_kernel<8>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, m, tab, x, part, pstride);
+  else
+    hipLaunchKernelGGL((multi_dot_kernel<HIPEIG_MAX_COLS>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, m, tab, x, part, pstride);
+  HIPEIG_CHECK(hipGetLastError());
+  return 0;
+}
+
+// Device-side result in ctx->d_scalars[0..m); optionally copied to the host.
+static int multi_dot_impl(hipeig_ctx* c, int64_t n, int m, const double* const* Y, const double* x,
+                          double* host_out) {
+  HIPEIG_REQUIRE(m >= 1 && m <= HIPEIG_MAX_COLS * HIPEIG_MAX_COLS, "too many columns for one call");
+  const int g = grid_for(n, 2);
+  for (int j0 = 0; j0 < m; j0 += HIPEIG_MAX_COLS) {
+    const int mm = (m - j0 < HIPEIG_MAX_COLS) ? (m - j0) : HIPEIG_MAX_COLS;
+    if (multi_dot_launch(c, n, mm, Y + j0, x, g, m, j0)) return 1;
+  }
+  return finalize_to_host(c, g, m, host_out);
+}
+
+extern "C" int hipeig_multi_dot(hipeig_ctx* c, int64_t n, int m, const double* const* Y,
+                                const double* x, double* out) {
+  int done = 0;
+  const int cap = HIPEIG_MAX_COLS * HIPEIG_MAX_COLS;
+  while (done < m) {
+    const int mm = (m - done < cap) ? (m - done) : cap;
+    int rc = multi_dot_impl(c, n, mm, Y + done, x, out + done);
+    if (rc) return rc;
+    done += mm;
+  }
+  return 0;
+}
+
+extern "C" int hipeig_gram(hipeig_ctx* c, int64_t n, int ma, const double* const* A, int mb,
+                           const double* const* B, double* out) {
+  HIPEIG_REQUIRE(ma >= 1 && mb >= 1, "empty set");
+  // one multi_dot sweep per column of B: reads B_j once and the ma columns of A once.
+  double* col = (double*)malloc(sizeof(double) * ma);
+  HIPEIG_REQUIRE(col != nullptr, "out of host memory");
+  int rc = 0;
+  for (int j = 0; j < mb && !rc; ++j) {
+    rc = hipeig_multi_dot(c, n, ma, A, B[j], col);
+    for (int i = 0; i < ma; ++i) out[(size_t)i * mb + j] = col[i];
+  }
+  free(col);
+  return rc;
+}
+
+// ---- Gram-Schmidt ------------------------------------------------------------------------
+// reference MGS step (numpyVector.py:134-138): t1 = x.q and t2 = q.q in one sweep
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+mgs_dots_kernel(int64_t n, const double* __restrict__ x, const double* __restrict__ q,
+                double* __restrict__ partials) {
+  __shared__ double lds[4];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double a = 0.0, b = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double qv = q[i];
+    a = fma(x[i], qv, a);
+    b = fma(qv, qv, b);
+  }
+  a = block_reduce_sum(a, lds);
+  b = block_reduce_sum(b, lds);
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x] = a;
+    partials[2 * blockIdx.x + 1] = b;
+  }
+}
+
+// x <- 1.0*x + (-1.0)*(q*(t1/t2)): the reference's roundings, element by element
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+mgs_update_kernel(int64_t n, const double* __restrict__ t, const double* __restrict__ q,
+                  double* __restrict__ x) {
+  const double coef = t[0] / t[1];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double proj = __dmul_rn(q[i], coef);
+    x[i] = __dadd_rn(x[i], -proj);
+  }
+}
+
+extern "C" int hipeig_orthonormalize(hipeig_ctx* c, int64_t n, int m, const double* const* Y,
+                                     double* x, double lindep, int method, double* innerprod,
+                                     int* is_lindep) {
+  HIPEIG_REQUIRE(innerprod && is_lindep, "null outputs");
+  HIPEIG_REQUIRE(method == 0 || method == 1, "method must be 0 (MGS) or 1 (CGS2)");
+  if (method == 0) {
+    const int g = grid_for(n, 4);
+    for (int j = 0; j < m; ++j) {
+      hipLaunchKernelGGL(mgs_dots_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, x, Y[j], c->d_partials);
+      HIPEIG_CHECK(hipGetLastError());
+      if (finalize_to_host(c, g, 2, nullptr)) return 4;
+      hipLaunchKernelGGL(mgs_update_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, c->d_scalars, Y[j], x);
+      HIPEIG_CHECK(hipGetLastError());
+    }
+  } else {
+    const int cap = HIPEIG_MAX_COLS * HIPEIG_MAX_COLS;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int j0 = 0; j0 < m; j0 += cap) {
+        const int mm = (m - j0 < cap) ? (m - j0) : cap;
+        if (multi_dot_impl(c, n, mm, Y + j0, x, nullptr)) return 4;       // coefficients stay on the device
+        if (lincomb_impl(c, n, mm, nullptr, c->d_scalars, -1.0, Y + j0, x, 1)) return 4;
+      }
+    }
+  }
+  double ip = 0.0;
+  int rc = hipeig_dot(c, n, x, x, &ip);
+  if (rc) return rc;
+  *innerprod = ip;
+  if (ip > lindep) {
+    *is_lindep = 0;
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 4)), dim3(HIPEIG_BLOCK), 0, c->stream, n, sqrt(ip), 1, x, x);
+    HIPEIG_CHECK(hipGetLastError());
+  } else {
+    *is_lindep = 1;
+  }
+  return 0;
+}

@@ -1,0 +1,152 @@
+// RCCL glue: one process per GPU, communicator attached to the context.
+//
+// librccl.so is opened lazily with dlopen so that single-GPU use neither loads nor needs
+// it.  Only three collectives exist on this path: an all-gather of
+// the operand slice before every operator application, a SUM all-reduce after every
+// reduction, and a tiny all-gather of the row counts when an operator is created.
+#include <dlfcn.h>
+#include "common.h"
+
+typedef void* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId_t;
+enum { NCCL_SUM = 0, NCCL_INT64 = 4, NCCL_FLOAT64 = 8 };
+
+struct RcclApi {
+  void* handle;
+  int (*GetUniqueId)(ncclUniqueId_t*);
+  int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId_t, int);
+  int (*CommDestroy)(ncclComm_t);
+  int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
+  int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t);
+  const char* (*GetErrorString)(int);
+};
+static RcclApi g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+static int load_rccl() {
+  if (g_rccl.handle) return 0;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* h = nullptr;
+  for (const char* nm : names) {
+    h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) {
+    hipeig_set_error("cannot dlopen librccl.so: %s", dlerror());
+    return 3;
+  }
+#define LOAD(field, sym)                                              \
+  *(void**)(&g_rccl.field) = dlsym(h, sym);                           \
+  if (!g_rccl.field) {                                                \
+    hipeig_set_error("librccl.so lacks symbol %s", sym);              \
+    return 3;                                                         \
+  }
+  LOAD(GetUniqueId, "ncclGetUniqueId");
+  LOAD(CommInitRank, "ncclCommInitRank");
+  LOAD(CommDestroy, "ncclCommDestroy");
+  LOAD(AllReduce, "ncclAllReduce");
+  LOAD(AllGather, "ncclAllGather");
+  LOAD(GetErrorString, "ncclGetErrorString");
+#undef LOAD
+  g_rccl.handle = h;
+  return 0;
+}
+
+#define RCCL_CHECK(expr)                                                                  \
+  do {                                                                                    \
+    int _r = (expr);                                                                      \
+    if (_r != 0) {                                                                        \
+      hipeig_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, g_rccl.GetErrorString(_r)); \
+      return 4;                                                                           \
+    }                                                                                     \
+  } while (0)
+
+extern "C" int hipeig_comm_unique_id(void* id128) {
+  if (load_rccl()) return 3;
+  ncclUniqueId_t id;
+  RCCL_CHECK(g_rccl.GetUniqueId(&id));
+  memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+
+extern "C" int hipeig_comm_init(hipeig_ctx* c, int nranks, int rank, const void* id128) {
+  HIPEIG_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank/nranks");
+  HIPEIG_REQUIRE(c->comm == nullptr, "communicator already attached");
+  if (load_rccl()) return 3;
+  HIPEIG_CHECK(hipSetDevice(c->device));
+  ncclUniqueId_t id;
+  memcpy(&id, id128, sizeof(id));
+  ncclComm_t comm = nullptr;
+  RCCL_CHECK(g_rccl.CommInitRank(&comm, nranks, id, rank));
+  c->comm = comm;
+  c->nranks = nranks;
+  c->rank = rank;
+  c->row_counts = (int64_t*)calloc((size_t)nranks, sizeof(int64_t));
+  return 0;
+}
+
+extern "C" int hipeig_comm_destroy(hipeig_ctx* c) {
+  if (c->comm) {
+    hipStreamSynchronize(c->stream);
+    g_rccl.CommDestroy((ncclComm_t)c->comm);
+    c->comm = nullptr;
+  }
+  c->nranks = 1;
+  c->rank = 0;
+  return 0;
+}
+
+extern "C" int hipeig_comm_info(hipeig_ctx* c, int* nranks, int* rank) {
+  if (nranks) *nranks = c->nranks;
+  if (rank) *rank = c->rank;
+  return 0;
+}
+
+// SUM all-reduce of `count` doubles in place on the compute stream.
+int hipeig_allreduce_sum(hipeig_ctx* c, double* d_buf, int count) {
+  if (!c->comm || c->nranks == 1) return 0;
+  RCCL_CHECK(g_rccl.AllReduce(d_buf, d_buf, (size_t)count, NCCL_FLOAT64, NCCL_SUM,
+                              (ncclComm_t)c->comm, c->stream));
+  return 0;
+}
+
+// Gather the row counts of every rank (host result in ctx->row_counts) and size the
+// gathered-operand buffer: rank r's slice lives at x_full + r*stride, stride = max count.
+int hipeig_comm_setup_rows(hipeig_ctx* c, int64_t nrows_local, int64_t* stride_out) {
+  if (!c->comm || c->nranks == 1) {
+    *stride_out = nrows_local;
+    return 0;
+  }
+  int64_t* d = (int64_t*)c->d_scalars;
+  HIPEIG_CHECK(hipMemcpyAsync(d + c->rank, &nrows_local, sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+  RCCL_CHECK(g_rccl.AllGather(d + c->rank, d, 1, NCCL_INT64, (ncclComm_t)c->comm, c->stream));
+  HIPEIG_CHECK(hipMemcpyAsync(c->row_counts, d, sizeof(int64_t) * c->nranks, hipMemcpyDeviceToHost, c->stream));
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  int64_t stride = 0;
+  for (int r = 0; r < c->nranks; ++r) stride = c->row_counts[r] > stride ? c->row_counts[r] : stride;
+  const int64_t need = stride * c->nranks;
+  if (need > c->x_full_n) {
+    if (c->x_full) HIPEIG_CHECK(hipFree(c->x_full));
+    HIPEIG_CHECK(hipMalloc((void**)&c->x_full, (size_t)need * sizeof(double)));
+    HIPEIG_CHECK(hipMemsetAsync(c->x_full, 0, (size_t)need * sizeof(double), c->stream));
+    c->x_full_n = need;
+  }
+  *stride_out = stride;
+  return 0;
+}
+
+// All-gather of the operand: every rank contributes its slice, in place inside x_full.
+int hipeig_allgather_x(hipeig_ctx* c, const double* x_local, int64_t n_local,
+                       const double** x_full_out) {
+  if (!c->comm || c->nranks == 1) {
+    *x_full_out = x_local;
+    return 0;
+  }
+  const int64_t stride = c->x_full_n / c->nranks;
+  double* mine = c->x_full + (int64_t)c->rank * stride;
+  HIPEIG_CHECK(hipMemcpyAsync(mine, x_local, (size_t)n_local * sizeof(double),
+                              hipMemcpyDeviceToDevice, c->stream));
+  RCCL_CHECK(g_rccl.AllGather(mine, c->x_full, (size_t)stride, NCCL_FLOAT64,
+                              (ncclComm_t)c->comm, c->stream));
+  *x_full_out = c->x_full;
+  return 0;
+}

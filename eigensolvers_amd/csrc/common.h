@@ -1,0 +1,139 @@
+// Internal definitions shared by the translation units of libhipeig.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/hipeig.h"
+
+#define HIPEIG_WAVE 64
+#define HIPEIG_BLOCK 256                 // 4 wavefronts per workgroup
+#define HIPEIG_MAX_PARTIALS 2048         // reduction grid cap: 256 CUs x 8 workgroups
+#define HIPEIG_MAX_COLS 16               // basis columns handled per tall-skinny launch
+
+void hipeig_set_error(const char* fmt, ...);
+
+#define HIPEIG_CHECK(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      hipeig_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return 1;                                                                         \
+    }                                                                                   \
+  } while (0)
+
+#define HIPEIG_REQUIRE(cond, msg)                                                       \
+  do {                                                                                  \
+    if (!(cond)) {                                                                      \
+      hipeig_set_error("%s:%d: requirement failed: %s (%s)", __FILE__, __LINE__, #cond, msg); \
+      return 2;                                                                         \
+    }                                                                                   \
+  } while (0)
+
+// Device-resident recurrence state of the MINRES driver (see minres.hip).
+struct MinresState {
+  double beta1, beta, oldb, alfa;
+  double dbar, epsln, oldeps, delta, gbar, gamma, cs, sn, phi, phibar;
+  double tnorm2, gmax, gmin, root;
+  double Anorm, ynorm, rnorm, test1, test2, Acond;
+  double s;          // 1/beta of the Lanczos vector being built (v = s*r)
+  double denom;      // 1/gamma
+  int itn;           // completed iterations
+  int istop;         // SciPy stop code, 0 = running
+  int pending_m1;    // istop = -1 requested at itn == 1
+  int done;          // iteration finished: later kernels of the chunk exit immediately
+};
+
+struct hipeig_ctx {
+  int device;
+  int num_cu;
+  hipStream_t stream;        // compute
+  hipStream_t comm_stream;   // collectives / copies overlapped with compute
+  hipEvent_t ev0, ev1, ev_comm;
+  // reduction workspace
+  double* d_partials;        // HIPEIG_MAX_PARTIALS * (HIPEIG_MAX_COLS*HIPEIG_MAX_COLS) doubles
+  size_t partials_doubles;
+  double* d_scalars;         // small device scalar area (results of reductions)
+  double* h_scalars;         // pinned host mirror
+  size_t scalars_doubles;
+  const double** d_ptrs;     // device pointer tables for tall-skinny kernels
+  const double** h_ptrs;     // pinned staging of the same
+  size_t ptrs_count;
+  // MINRES workspace (6 vectors) cached across solves
+  double* mr_ws;
+  int64_t mr_ws_n;
+  MinresState* d_mr_state;   // ring of 3
+  MinresState* h_mr_state;   // pinned
+  // distributed
+  void* comm;                // ncclComm_t
+  int nranks, rank;
+  double* x_full;            // all-gathered operand of the operator
+  int64_t x_full_n;
+  int64_t* row_counts;       // rows per rank (host), length nranks
+};
+
+struct hipeig_csr {
+  int64_t nrows, ncols, nnz, row_offset;
+  int32_t* d_rowptr;         // nrows+1
+  int32_t* d_col;            // nnz
+  double* d_val;             // nnz
+  int32_t* d_row_blocks;     // n_row_blocks+1 row indices: block b owns rows [rb[b], rb[b+1])
+  int32_t n_row_blocks;
+  int variant;               // 0 = auto, 1 = CSR-vector, 2 = CSR-stream (LDS-staged)
+  int lanes_per_row;         // sub-wave width used to reduce one row
+  int64_t col_stride;        // x_full stride per rank when columns were remapped (0 = global)
+  int64_t bytes;
+};
+
+// ---- collectives (comm.hip); no-ops without a communicator ---------------------------
+int hipeig_comm_setup_rows(hipeig_ctx* ctx, int64_t nrows_local, int64_t* stride_out);
+int hipeig_allreduce_sum(hipeig_ctx* ctx, double* d_buf, int count);
+int hipeig_allgather_x(hipeig_ctx* ctx, const double* x_local, int64_t n_local,
+                       const double** x_full_out);
+
+// ---- device helpers ------------------------------------------------------------------
+__device__ __forceinline__ double wave_reduce_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;   // valid in lane 0
+}
+
+// Sum over the workgroup; result valid in thread 0.  lds must hold >= 4 doubles.
+__device__ __forceinline__ double block_reduce_sum(double v, double* lds) {
+  v = wave_reduce_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) lds[wid] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    r = lds[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r += lds[w];
+  }
+  __syncthreads();
+  return r;
+}
+
+// Every thread of the workgroup obtains the fixed-order sum of p[0..count) (count <=
+// HIPEIG_MAX_PARTIALS).  Used in kernel prologues so that a reduction never needs its own
+// launch or a host round trip; every workgroup computes the identical value.
+__device__ __forceinline__ double block_sum_partials(const double* __restrict__ p, int count,
+                                                     double* lds) {
+  double a = 0.0;
+  for (int i = threadIdx.x; i < count; i += blockDim.x) a += p[i];
+  a = wave_reduce_sum(a);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) lds[wid] = a;
+  __syncthreads();
+  double r = lds[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r += lds[w];
+  __syncthreads();
+  return r;
+}
+
+static inline int grid_for(int64_t n, int per_thread) {
+  int64_t g = (n + (int64_t)HIPEIG_BLOCK * per_thread - 1) / ((int64_t)HIPEIG_BLOCK * per_thread);
+  if (g < 1) g = 1;
+  if (g > HIPEIG_MAX_PARTIALS) g = HIPEIG_MAX_PARTIALS;
+  return (int)g;
+}

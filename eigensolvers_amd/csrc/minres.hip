@@ -1,0 +1,311 @@
+// Device-resident MINRES for sign*(sigma*I - H) x = b  (NumpyVector.solve with
+// linearSolver="minres", numpyVector.py:147-178; the recurrences are SciPy 1.15.3's
+// scipy.sparse.linalg.minres, the third-party routine the reference calls at :163).
+//
+// One iteration = three kernels, no host round trip:
+//   KA  y = A v - (beta/oldb) r1,  v = r2/beta        (CSR sweep, fused)   + partial <v,y>
+//   KC  y -= (alfa/beta) r2                                              + partial <y,y>
+//   KD  w = (v - oldeps*w1 - delta*w2)/gamma ; x += phi*w                 + partial <x,x>
+// The recurrence scalars live in a ring of three MinresState records in device memory: each
+// kernel reads one record and workgroup 0 writes the next, every workgroup having first
+// reduced the previous kernel's <= 2048 partial sums in its prologue (fixed order, so all
+// workgroups obtain the identical value).  The stopping tests of iteration k are evaluated
+// in the prologue of KA(k+1) (or by minres_check_kernel at the end of a chunk); once `done`
+// is set the remaining kernels of the chunk return immediately and x is left untouched.
+#include <math.h>
+#include "spmv_device.h"
+
+CsrView hipeig_csr_view(const hipeig_csr* A);
+int hipeig_spmv_grid(const hipeig_csr* A, int variant);
+
+#define MR_EPS 2.220446049250313e-16
+
+struct MinresArgs {
+  double sigma, sign, rtol;
+  int maxiter;
+  int nA, nC, nD;                 // number of valid partials of KA / KC / KD (1 = already reduced)
+  const double* pA; const double* pC; const double* pD;
+};
+
+__device__ __forceinline__ double sum_or_value(const double* p, int count, double* lds) {
+  if (count == 1) return p[0];
+  return block_sum_partials(p, count, lds);
+}
+
+// Stopping tests of the iteration that has just completed (SciPy order).  S is a private copy.
+__device__ __forceinline__ void minres_tests(MinresState& S, double xx, const MinresArgs& a) {
+  if (S.itn == 0 || S.done) return;
+  S.Anorm = sqrt(S.tnorm2);
+  S.ynorm = sqrt(xx);
+  const double epsx = S.Anorm * S.ynorm * MR_EPS;
+  S.rnorm = S.phibar;
+  S.test1 = (S.ynorm == 0.0 || S.Anorm == 0.0) ? INFINITY : S.rnorm / (S.Anorm * S.ynorm);
+  S.test2 = (S.Anorm == 0.0) ? INFINITY : S.root / S.Anorm;
+  S.Acond = S.gmax / S.gmin;
+  int istop = S.pending_m1 ? -1 : 0;
+  if (istop == 0) {
+    const double t1 = 1.0 + S.test1, t2 = 1.0 + S.test2;
+    if (t2 <= 1.0) istop = 2;
+    if (t1 <= 1.0) istop = 1;
+    if (S.itn >= a.maxiter) istop = 6;
+    if (S.Acond >= 0.1 / MR_EPS) istop = 4;
+    if (epsx >= S.beta1) istop = 3;
+    if (S.test2 <= a.rtol) istop = 2;
+    if (S.test1 <= a.rtol) istop = 1;
+  }
+  S.istop = istop;
+  if (istop != 0) S.done = 1;
+}
+
+struct MinresRowEpilogue {
+  double sigma, sign, s, c1;
+  int use_r1;
+  const double* __restrict__ r2l;   // local slice of r2 (v = s*r2)
+  const double* __restrict__ r1;
+  double* __restrict__ y;
+  __device__ __forceinline__ void row(int64_t r, double sum, double& acc) const {
+    const double v = s * r2l[r];
+    double yv = sign * (__dmul_rn(sigma, v) - s * sum);
+    if (use_r1) yv -= c1 * r1[r];
+    y[r] = yv;
+    acc = fma(v, yv, acc);
+  }
+};
+
+template <int VARIANT>
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+minres_ka_kernel(CsrView A, const double* __restrict__ xg, MinresArgs a, const MinresState* __restrict__ Sin,
+                 MinresState* __restrict__ Sout, const double* __restrict__ r2l,
+                 const double* __restrict__ r1, double* __restrict__ y, double* __restrict__ partials) {
+  __shared__ double prod[VARIANT == 2 ? SPMV_NNZ_PER_BLOCK : 8];
+  __shared__ double red[4];
+  MinresState S = *Sin;
+  const double xx = (S.itn > 0 && !S.done) ? sum_or_value(a.pD, a.nD, red) : 0.0;
+  minres_tests(S, xx, a);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
+  if (S.done) return;
+  MinresRowEpilogue epi;
+  epi.sigma = a.sigma; epi.sign = a.sign; epi.s = S.s;
+  epi.use_r1 = S.itn >= 1;
+  epi.c1 = epi.use_r1 ? S.beta / S.oldb : 0.0;
+  epi.r2l = r2l; epi.r1 = r1; epi.y = y;
+  double acc = 0.0;
+  if (VARIANT == 2) csr_stream_sweep(A, xg, epi, acc, prod);
+  else csr_vector_sweep(A, xg, epi, acc);
+  acc = block_reduce_sum(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+minres_kc_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, MinresState* __restrict__ Sout,
+                 const double* __restrict__ r2, double* __restrict__ y, double* __restrict__ partials) {
+  __shared__ double red[4];
+  MinresState S = *Sin;
+  if (S.done) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
+    return;
+  }
+  S.alfa = sum_or_value(a.pA, a.nA, red);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
+  const double c = S.alfa / S.beta;
+  const int64_t n2 = n >> 1;
+  const double2* r22 = reinterpret_cast<const double2*>(r2);
+  double2* y2 = reinterpret_cast<double2*>(y);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    const double2 rv = r22[i];
+    double2 yv = y2[i];
+    yv.x -= c * rv.x; yv.y -= c * rv.y;
+    y2[i] = yv;
+    acc = fma(yv.x, yv.x, acc); acc = fma(yv.y, yv.y, acc);
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const double yv = y[n - 1] - c * r2[n - 1];
+    y[n - 1] = yv;
+    acc = fma(yv, yv, acc);
+  }
+  acc = block_reduce_sum(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+minres_kd_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, MinresState* __restrict__ Sout,
+                 const double* __restrict__ r2old, const double* __restrict__ w1, const double* __restrict__ w2,
+                 double* __restrict__ w, double* __restrict__ x, double* __restrict__ partials) {
+  __shared__ double red[4];
+  MinresState S = *Sin;
+  if (S.done) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
+    return;
+  }
+  const double bb = sum_or_value(a.pC, a.nC, red);
+  const double s_old = S.s;
+  // ---- scalar recurrences (every thread, identical) ----
+  S.oldb = S.beta;
+  S.beta = sqrt(bb);
+  S.tnorm2 += S.alfa * S.alfa + S.oldb * S.oldb + S.beta * S.beta;
+  if (S.itn == 0 && S.beta / S.beta1 <= 10.0 * MR_EPS) S.pending_m1 = 1;
+  S.oldeps = S.epsln;
+  S.delta = S.cs * S.dbar + S.sn * S.alfa;
+  S.gbar = S.sn * S.dbar - S.cs * S.alfa;
+  S.epsln = S.sn * S.beta;
+  S.dbar = -S.cs * S.beta;
+  S.root = sqrt(S.gbar * S.gbar + S.dbar * S.dbar);
+  S.gamma = fmax(sqrt(S.gbar * S.gbar + S.beta * S.beta), MR_EPS);
+  S.cs = S.gbar / S.gamma;
+  S.sn = S.beta / S.gamma;
+  S.phi = S.cs * S.phibar;
+  S.phibar = S.sn * S.phibar;
+  S.denom = 1.0 / S.gamma;
+  S.gmax = fmax(S.gmax, S.gamma);
+  S.gmin = fmin(S.gmin, S.gamma);
+  S.s = 1.0 / S.beta;
+  S.itn += 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
+  // ---- w = (v - oldeps*w1 - delta*w2)*denom ; x += phi*w ----
+  const double oldeps = S.oldeps, delta = S.delta, denom = S.denom, phi = S.phi;
+  const int64_t n2 = n >> 1;
+  const double2* r2 = reinterpret_cast<const double2*>(r2old);
+  const double2* w12 = reinterpret_cast<const double2*>(w1);
+  const double2* w22 = reinterpret_cast<const double2*>(w2);
+  double2* wn2 = reinterpret_cast<double2*>(w);
+  double2* x2 = reinterpret_cast<double2*>(x);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    const double2 rv = r2[i], a1 = w12[i], a2 = w22[i];
+    double2 xv = x2[i], wn;
+    wn.x = (s_old * rv.x - oldeps * a1.x - delta * a2.x) * denom;
+    wn.y = (s_old * rv.y - oldeps * a1.y - delta * a2.y) * denom;
+    xv.x += phi * wn.x; xv.y += phi * wn.y;
+    wn2[i] = wn;
+    x2[i] = xv;
+    acc = fma(xv.x, xv.x, acc); acc = fma(xv.y, xv.y, acc);
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    const double wn = (s_old * r2old[i] - oldeps * w1[i] - delta * w2[i]) * denom;
+    const double xv = x[i] + phi * wn;
+    w[i] = wn; x[i] = xv;
+    acc = fma(xv, xv, acc);
+  }
+  acc = block_reduce_sum(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// End-of-chunk evaluation of the stopping tests (what KA's prologue would do next).
+__global__ void minres_check_kernel(MinresArgs a, MinresState* __restrict__ S0) {
+  __shared__ double red[4];
+  MinresState S = *S0;
+  const double xx = (S.itn > 0 && !S.done) ? sum_or_value(a.pD, a.nD, red) : 0.0;
+  minres_tests(S, xx, a);
+  if (threadIdx.x == 0) *S0 = S;
+}
+
+__global__ void sum_partials_kernel(const double* __restrict__ p, int count, double* __restrict__ out) {
+  __shared__ double red[4];
+  const double v = block_sum_partials(p, count, red);
+  if (threadIdx.x == 0) *out = v;
+}
+
+extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double sign, const double* b,
+                             double* x, double rtol, int maxiter, int* info, double out_stats[8]) {
+  HIPEIG_REQUIRE(info != nullptr, "null info");
+  HIPEIG_REQUIRE(sign == 1.0 || sign == -1.0, "sign must be +1 or -1");
+  HIPEIG_REQUIRE(maxiter >= 1, "maxiter must be positive");
+  HIPEIG_REQUIRE(b != x, "x must not alias b");
+  const int64_t n = A->nrows;
+  *info = 0;
+  if (out_stats) memset(out_stats, 0, 8 * sizeof(double));
+  if (hipeig_vec_fill(c, x, n, 0.0)) return 1;
+  double bb = 0.0;
+  if (hipeig_dot(c, n, b, b, &bb)) return 1;
+  if (bb == 0.0) return 0;            // beta1 == 0: the exact solution is x0 = 0
+
+  // workspace: R[3] (r1, r2, y rotate) and W[3] (w1, w2, w rotate)
+  if (c->mr_ws_n < n) {
+    if (c->mr_ws) HIPEIG_CHECK(hipFree(c->mr_ws));
+    c->mr_ws = nullptr; c->mr_ws_n = 0;
+    const int64_t npad = (n + 31) & ~(int64_t)31;
+    HIPEIG_CHECK(hipMalloc((void**)&c->mr_ws, (size_t)npad * 6 * sizeof(double)));
+    c->mr_ws_n = n;
+  }
+  const int64_t npad = (c->mr_ws_n + 31) & ~(int64_t)31;
+  double* R[3] = {c->mr_ws, c->mr_ws + npad, c->mr_ws + 2 * npad};
+  double* W[3] = {c->mr_ws + 3 * npad, c->mr_ws + 4 * npad, c->mr_ws + 5 * npad};
+  HIPEIG_CHECK(hipMemcpyAsync(R[0], b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPEIG_CHECK(hipMemsetAsync(W[0], 0, (size_t)npad * 3 * sizeof(double), c->stream));
+
+  MinresState* h = c->h_mr_state;
+  memset(h, 0, sizeof(MinresState));
+  h->beta1 = sqrt(bb);
+  h->beta = h->beta1;
+  h->phibar = h->beta1;
+  h->cs = -1.0;
+  h->gmin = 1.7976931348623157e308;
+  h->s = 1.0 / h->beta;
+  MinresState* V = c->d_mr_state;
+  HIPEIG_CHECK(hipMemcpyAsync(V, h, sizeof(MinresState), hipMemcpyHostToDevice, c->stream));
+
+  const int variant = A->variant ? A->variant : 2;
+  const CsrView view = hipeig_csr_view(A);
+  const int gA = hipeig_spmv_grid(A, variant);
+  const int gE = grid_for(n, 4);
+  double* pA = c->d_partials;
+  double* pC = c->d_partials + HIPEIG_MAX_PARTIALS;
+  double* pD = c->d_partials + 2 * HIPEIG_MAX_PARTIALS;
+  const bool dist = c->comm && c->nranks > 1;
+  double* red = c->d_scalars + 2048;    // reduced sums for the distributed path
+  MinresArgs a;
+  a.sigma = sigma; a.sign = sign; a.rtol = rtol; a.maxiter = maxiter;
+  a.pA = dist ? red + 0 : pA; a.nA = dist ? 1 : gA;
+  a.pC = dist ? red + 1 : pC; a.nC = dist ? 1 : gE;
+  a.pD = dist ? red + 2 : pD; a.nD = dist ? 1 : gE;
+
+  const int chunk = 16;
+  int k = 0;
+  while (k < maxiter) {
+    const int kend = (k + chunk < maxiter) ? k + chunk : maxiter;
+    for (; k < kend; ++k) {
+      double* r2 = R[k % 3];
+      double* yb = R[(k + 1) % 3];
+      double* r1 = R[(k + 2) % 3];
+      double* wn = W[k % 3];
+      double* w1 = W[(k + 1) % 3];
+      double* w2 = W[(k + 2) % 3];
+      const double* xg = nullptr;
+      if (hipeig_allgather_x(c, r2, n, &xg)) return 4;
+      if (variant == 1)
+        hipLaunchKernelGGL((minres_ka_kernel<1>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream, view, xg, a, V + 0, V + 1, r2, r1, yb, pA);
+      else
+        hipLaunchKernelGGL((minres_ka_kernel<2>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream, view, xg, a, V + 0, V + 1, r2, r1, yb, pA);
+      if (dist) {
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pA, gA, red + 0);
+        if (hipeig_allreduce_sum(c, red + 0, 1)) return 4;
+      }
+      hipLaunchKernelGGL(minres_kc_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 1, V + 2, r2, yb, pC);
+      if (dist) {
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pC, gE, red + 1);
+        if (hipeig_allreduce_sum(c, red + 1, 1)) return 4;
+      }
+      hipLaunchKernelGGL(minres_kd_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 2, V + 0, r2, w1, w2, wn, x, pD);
+      if (dist) {
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pD, gE, red + 2);
+        if (hipeig_allreduce_sum(c, red + 2, 1)) return 4;
+      }
+    }
+    HIPEIG_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(minres_check_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, a, V + 0);
+    HIPEIG_CHECK(hipMemcpyAsync(h, V, sizeof(MinresState), hipMemcpyDeviceToHost, c->stream));
+    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+    if (h->done) break;
+  }
+  HIPEIG_REQUIRE(h->done, "MINRES left the iteration loop without a stop code");
+  *info = (h->istop == 6) ? maxiter : 0;
+  if (out_stats) {
+    out_stats[0] = h->itn; out_stats[1] = h->istop; out_stats[2] = h->rnorm; out_stats[3] = h->Anorm;
+    out_stats[4] = h->ynorm; out_stats[5] = h->test1; out_stats[6] = h->test2; out_stats[7] = h->Acond;
+  }
+  return 0;
+}

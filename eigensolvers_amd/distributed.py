@@ -1,0 +1,60 @@
+"""Row partitioning and communicator bootstrap for the multi-GPU path (one process per GPU).
+
+The operator is split into contiguous row slabs, one per rank;
+every vector is split the same way.  The only exchanges on the path are an all-gather of
+the operand slice before each operator application and a SUM all-reduce after each
+reduction, both issued by ``libhipeig.so`` through RCCL on its compute stream.  The host
+side only has to (a) agree on the row ranges and (b) distribute RCCL's 128-byte unique id,
+which is done here over ``torch.distributed`` (gloo) - torch is plumbing for the
+rendezvous, no tensor of the hot path ever goes through it.
+"""
+import os
+
+
+def row_range(N, nranks, rank):
+    """Contiguous balanced slab [begin, end) of rank ``rank``; the first N % nranks ranks
+    hold one extra row."""
+    base, extra = divmod(int(N), int(nranks))
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def all_row_ranges(N, nranks):
+    return [row_range(N, nranks, r) for r in range(nranks)]
+
+
+def world_from_env():
+    """(rank, world_size, local_rank) from the torchrun environment (defaults: single)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init_process_group_gloo():
+    """Join the gloo group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="gloo")
+    return dist
+
+
+def broadcast_bytes(payload, nbytes, src=0):
+    """Broadcast a fixed-size byte string from ``src`` over the gloo group."""
+    import torch
+    import torch.distributed as dist
+    buf = torch.zeros(nbytes, dtype=torch.uint8)
+    if dist.get_rank() == src:
+        buf = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
+    dist.broadcast(buf, src=src)
+    return bytes(buf.numpy().tobytes())
+
+
+def attach_rccl(ctx):
+    """Create the RCCL communicator of ``ctx`` for the current gloo group (collective)."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    uid = ctx.new_unique_id() if rank == 0 else b"\0" * 128
+    uid = broadcast_bytes(uid, 128, src=0)
+    ctx.attach_comm(world, rank, uid)
+    return rank, world

@@ -1,0 +1,452 @@
+"""``HipVector``: the MI355X backend of the ``AbstractVector`` plugin surface.
+
+It sits beside the reference's ``NumpyVector`` (numpyVector.py:23-238): same constructor
+shape ``HipVector(array, options)``, same ``options["linearSystemArgs"]`` keys, same
+methods and static hooks, same error behaviour - but the data is a device-resident fp64
+buffer and every operation is a call into ``libhipeig.so`` (hand-written gfx950 kernels).
+The operator handed to the solver must be a ``HipCsrOperator`` (device-resident CSR);
+``HipCsrOperator.from_scipy`` / ``from_dense`` / ``generate`` create one.
+
+With a communicator attached to the context (``HipContext.attach_comm``) a ``HipVector``
+holds the LOCAL row slice of a row-partitioned global vector and the same calls become
+collective: reductions all-reduce, operator applications all-gather the operand.
+"""
+import ctypes as C
+import os
+import weakref
+
+import numpy as np
+
+from . import _lib
+from .abstract_vector import AbstractVector, LINDEP_DEFAULT_VALUE
+
+_ORTHO_METHODS = {"mgs": 0, "cgs2": 1}
+
+
+def _ptr_table(bufs):
+    arr = (C.c_void_p * len(bufs))(*[b.ptr for b in bufs])
+    return C.cast(arr, C.POINTER(C.c_void_p)), arr
+
+
+class HipContext:
+    """Owns the device context handle (streams, workspaces, optional RCCL communicator)."""
+
+    _default = None
+
+    def __init__(self, device=None):
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        h = C.c_void_p()
+        _lib.call("hipeig_ctx_create", int(device), C.byref(h))
+        self.handle = h
+        self.device = int(device)
+        self.nranks, self.rank = 1, 0
+        self._pool = {}
+        self._finalizer = weakref.finalize(self, HipContext._destroy, h, self._pool)
+
+    @staticmethod
+    def _destroy(handle, pool):
+        lib = _lib.load()
+        for ptrs in pool.values():
+            for p in ptrs:
+                lib.hipeig_vec_free(handle, C.c_void_p(p))
+        pool.clear()
+        lib.hipeig_ctx_destroy(handle)
+
+    @classmethod
+    def default(cls):
+        if cls._default is None:
+            cls._default = cls()
+        return cls._default
+
+    # ---- communicator -------------------------------------------------------------
+    @staticmethod
+    def new_unique_id():
+        buf = C.create_string_buffer(128)
+        _lib.call("hipeig_comm_unique_id", C.cast(buf, C.c_void_p))
+        return bytes(buf.raw)
+
+    def attach_comm(self, nranks, rank, unique_id):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _lib.call("hipeig_comm_init", self.handle, int(nranks), int(rank), C.cast(buf, C.c_void_p))
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    # ---- memory -------------------------------------------------------------------
+    def alloc(self, n):
+        free = self._pool.get(n)
+        if free:
+            return DeviceBuffer(self, free.pop(), n)
+        p = C.c_void_p()
+        _lib.call("hipeig_vec_alloc", self.handle, int(n), C.byref(p))
+        return DeviceBuffer(self, p.value, n)
+
+    def synchronize(self):
+        _lib.call("hipeig_ctx_sync", self.handle)
+
+    def device_info(self):
+        info = (C.c_int64 * 8)()
+        name = C.create_string_buffer(256)
+        _lib.call("hipeig_device_info", self.handle, info, name, 256)
+        return {"name": name.value.decode(), "cus": info[0], "wave": info[1], "hbm_total": info[2],
+                "hbm_free": info[3], "l2_bytes": info[4]}
+
+    def timer_start(self):
+        _lib.call("hipeig_timer_start", self.handle)
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _lib.call("hipeig_timer_stop", self.handle, C.byref(ms))
+        return float(ms.value)
+
+
+class DeviceBuffer:
+    """A device allocation of n doubles; returned to the context's pool when collected.
+
+    All work is ordered on one stream, so recycling a buffer without a sync is safe."""
+
+    __slots__ = ("ctx", "ptr", "n", "__weakref__")
+
+    def __init__(self, ctx, ptr, n):
+        self.ctx, self.ptr, self.n = ctx, ptr, n
+
+    def __del__(self):
+        try:
+            self.ctx._pool.setdefault(self.n, []).append(self.ptr)
+        except Exception:
+            pass
+
+
+class HipCsrOperator:
+    """Device-resident sparse symmetric operator (local rows of a row partition)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.handle = handle
+        info = (C.c_int64 * 8)()
+        _lib.call("hipeig_csr_info", handle, info)
+        self.nrows, self.ncols, self.nnz, self.row_offset = info[0], info[1], info[2], info[3]
+        self.device_bytes = info[5]
+        self.shape = (self.nrows, self.ncols)
+        self.dtype = np.dtype(np.float64)
+        self._finalizer = weakref.finalize(self, HipCsrOperator._destroy, ctx, handle)
+
+    @staticmethod
+    def _destroy(ctx, handle):
+        _lib.load().hipeig_csr_destroy(ctx.handle, handle)
+
+    @classmethod
+    def from_csr_arrays(cls, rowptr, col, val, ncols, row_offset=0, ctx=None):
+        ctx = ctx or HipContext.default()
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        h = C.c_void_p()
+        _lib.call("hipeig_csr_create", ctx.handle, len(rowptr) - 1, int(ncols), int(row_offset),
+                  rowptr.ctypes.data_as(C.POINTER(C.c_int64)), col.ctypes.data_as(C.POINTER(C.c_int32)),
+                  val.ctypes.data_as(C.POINTER(C.c_double)), C.byref(h))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_scipy(cls, A, row_begin=0, row_end=None, ctx=None):
+        """Upload rows [row_begin,row_end) of a scipy.sparse matrix (real, any format)."""
+        import scipy.sparse as sp
+        A = sp.csr_matrix(A)
+        if np.iscomplexobj(A.data):
+            raise TypeError("HipCsrOperator holds real fp64 operators")
+        row_end = A.shape[0] if row_end is None else row_end
+        sl = A[row_begin:row_end]
+        return cls.from_csr_arrays(sl.indptr, sl.indices, sl.data, A.shape[1], row_begin, ctx)
+
+    @classmethod
+    def from_dense(cls, M, ctx=None):
+        """Dense ndarray stored as a full CSR (every entry kept) - plumbing-size problems."""
+        M = np.asarray(M, dtype=np.float64)
+        n, m = M.shape
+        rowptr = np.arange(0, n * m + 1, m, dtype=np.int64)
+        col = np.tile(np.arange(m, dtype=np.int32), n)
+        return cls.from_csr_arrays(rowptr, col, M.ravel(), m, 0, ctx)
+
+    @classmethod
+    def generate(cls, N, nnz_row=64, seed=7, row_begin=0, row_end=None, ctx=None, **kw):
+        """Synthetic gapped random-sparse Hermitian operator built on the device
+        (bit-identical to ``generators.gapped_csr_host``)."""
+        from .generators import gapped_params
+        ctx = ctx or HipContext.default()
+        p = gapped_params(N, nnz_row, seed, **kw)
+        row_end = N if row_end is None else row_end
+        t = np.ascontiguousarray(p["targets"], dtype=np.float64)
+        h = C.c_void_p()
+        _lib.call("hipeig_csr_generate", ctx.handle, int(N), int(row_begin), int(row_end), p["K"],
+                  C.c_uint64(p["seed"]), p["eps"], C.c_uint32(p["thresh24"]),
+                  t.ctypes.data_as(C.POINTER(C.c_double)), len(t), C.byref(h))
+        return cls(ctx, h)
+
+    def set_variant(self, variant):
+        _lib.call("hipeig_csr_set_variant", self.handle, int(variant))
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        rp = np.empty(self.nrows + 1, dtype=np.int64)
+        col = np.empty(self.nnz, dtype=np.int32)
+        val = np.empty(self.nnz, dtype=np.float64)
+        _lib.call("hipeig_csr_download", self.ctx.handle, self.handle,
+                  rp.ctypes.data_as(C.POINTER(C.c_int64)), col.ctypes.data_as(C.POINTER(C.c_int32)),
+                  val.ctypes.data_as(C.POINTER(C.c_double)))
+        return sp.csr_matrix((val, col, rp), shape=(self.nrows, self.ncols))
+
+    def algorithmic_bytes(self):
+        """nnz*(8+4) + (nrows+1)*4 + 8*ncols (x once) + 8*nrows (y)."""
+        return self.nnz * 12 + (self.nrows + 1) * 4 + 8 * self.ncols + 8 * self.nrows
+
+    # y = H x on raw buffers
+    def apply(self, x, y):
+        _lib.call("hipeig_spmv", self.ctx.handle, self.handle, x.ptr, y.ptr)
+
+    def apply_shifted(self, sigma, x, y, reverse=False):
+        _lib.call("hipeig_spmv_shift", self.ctx.handle, self.handle, float(sigma),
+                  -1.0 if reverse else 1.0, x.ptr, y.ptr)
+
+    def __matmul__(self, v):
+        if isinstance(v, HipVector):
+            return v.applyOp(self)
+        return NotImplemented
+
+
+class HipVector(AbstractVector):
+    """Device-resident fp64 vector with the NumpyVector interface."""
+
+    def __init__(self, array, options=None, ctx=None):
+        given = {} if options is None else options
+        if isinstance(array, DeviceBuffer):
+            self._buf = array
+            self.ctx = array.ctx
+        else:
+            host = np.ascontiguousarray(array, dtype=np.float64)
+            if host.ndim != 1:
+                raise ValueError("HipVector holds 1-D vectors")
+            if np.iscomplexobj(array):
+                raise TypeError("HipVector is real fp64 (complex128 is the FEAST follow-up)")
+            self.ctx = ctx or HipContext.default()
+            self._buf = self.ctx.alloc(host.size)
+            _lib.call("hipeig_vec_upload", self.ctx.handle, self._buf.ptr,
+                      host.ctypes.data_as(C.c_void_p), host.size)
+        self.size = self._buf.n
+        self.shape = (self._buf.n,)
+        # numpyVector.py:29-36: defaults are written back into the caller's dict, which all
+        # vectors derived from this one then share
+        lsa = given.get("linearSystemArgs", dict())
+        lsa.setdefault("linearSolver", "minres")
+        lsa.setdefault("linearIter", 1000)
+        lsa.setdefault("linear_tol", 1e-4)
+        lsa.setdefault("linear_atol", 1e-4)
+        self.options = {"linearSystemArgs": lsa}
+        if "orthogonalization" in given:
+            self.options["orthogonalization"] = given["orthogonalization"]
+        self.last_solve_stats = None
+
+    # ---- helpers -------------------------------------------------------------------
+    def _new(self, buf):
+        return HipVector(buf, self.options)
+
+    @property
+    def array(self):
+        """Host copy of the (local) data - the reference's tests read ``.array``."""
+        out = np.empty(self._buf.n, dtype=np.float64)
+        _lib.call("hipeig_vec_download", self.ctx.handle, out.ctypes.data_as(C.c_void_p),
+                  self._buf.ptr, self._buf.n)
+        return out
+
+    # ---- properties ----------------------------------------------------------------
+    @property
+    def hasExactAddition(self):
+        return True
+
+    @property
+    def dtype(self):
+        return np.dtype(np.float64)
+
+    @property
+    def maxD(self):
+        return 0
+
+    # ---- arithmetic (out of place, numpyVector.py:57-64) ----------------------------
+    def _scaled(self, alpha):
+        if isinstance(alpha, complex) or np.iscomplexobj(alpha):
+            raise TypeError("HipVector is real fp64; complex scalars belong to the FEAST follow-up")
+        out = self.ctx.alloc(self._buf.n)
+        _lib.call("hipeig_scale", self.ctx.handle, self._buf.n, float(alpha), self._buf.ptr, out.ptr)
+        return self._new(out)
+
+    def __mul__(self, other):
+        return self._scaled(other)
+
+    def __rmul__(self, other):
+        return self._scaled(other)
+
+    def __truediv__(self, other):
+        out = self.ctx.alloc(self._buf.n)
+        _lib.call("hipeig_divide", self.ctx.handle, self._buf.n, float(other), self._buf.ptr, out.ptr)
+        return self._new(out)
+
+    def __imul__(self, other):
+        raise NotImplementedError          # numpyVector.py:66-67
+
+    def __itruediv__(self, other):
+        raise NotImplementedError          # numpyVector.py:69-70
+
+    def __len__(self):
+        return self._buf.n
+
+    # ---- instance methods -----------------------------------------------------------
+    def normalize(self):
+        nrm = C.c_double()
+        _lib.call("hipeig_normalize", self.ctx.handle, self._buf.n, self._buf.ptr, C.byref(nrm))
+        return self
+
+    def norm(self):
+        out = C.c_double()
+        _lib.call("hipeig_nrm2", self.ctx.handle, self._buf.n, self._buf.ptr, C.byref(out))
+        return float(out.value)
+
+    def real(self):
+        return self.copy()
+
+    def conjugate(self):
+        return self.copy()
+
+    def vdot(self, other, conjugate=True):
+        out = C.c_double()
+        _lib.call("hipeig_dot", self.ctx.handle, self._buf.n, self._buf.ptr, other._buf.ptr, C.byref(out))
+        return float(out.value)
+
+    def copy(self):
+        out = self.ctx.alloc(self._buf.n)
+        _lib.call("hipeig_vec_copy", self.ctx.handle, out.ptr, self._buf.ptr, self._buf.n)
+        return self._new(out)
+
+    def applyOp(self, other):
+        if not isinstance(other, HipCsrOperator):
+            raise TypeError("HipVector.applyOp needs a HipCsrOperator (device-resident CSR)")
+        out = self.ctx.alloc(other.nrows)
+        other.apply(self._buf, out)
+        return self._new(out)
+
+    def compress(self):
+        return self
+
+    # ---- static hooks ----------------------------------------------------------------
+    @staticmethod
+    def linearCombination(vectors, coeffs):
+        assert len(vectors) == len(coeffs)
+        v0 = vectors[0]
+        cf = np.ascontiguousarray(coeffs, dtype=np.float64)
+        out = v0.ctx.alloc(v0._buf.n)
+        tab, keep = _ptr_table([v._buf for v in vectors])
+        _lib.call("hipeig_lincomb", v0.ctx.handle, v0._buf.n, len(vectors),
+                  cf.ctypes.data_as(C.POINTER(C.c_double)), tab, out.ptr)
+        return v0._new(out)
+
+    @staticmethod
+    def linearCombinationBlock(vectors, coeffs):
+        """k combinations at once: out[c] = sum_j coeffs[j, c] * vectors[j]
+        (basisTransformation with a coefficient matrix, util_funcs.py:229-230)."""
+        v0 = vectors[0]
+        cm = np.ascontiguousarray(coeffs, dtype=np.float64)
+        m, k = cm.shape
+        assert m == len(vectors)
+        outs = [v0.ctx.alloc(v0._buf.n) for _ in range(k)]
+        tab, keep = _ptr_table([v._buf for v in vectors])
+        otab, okeep = _ptr_table(outs)
+        _lib.call("hipeig_lincomb_block", v0.ctx.handle, v0._buf.n, m, k,
+                  cm.ctypes.data_as(C.POINTER(C.c_double)), k, tab, otab)
+        return [v0._new(o) for o in outs]
+
+    @staticmethod
+    def orthogonalize_against_set(x, qs, lindep=LINDEP_DEFAULT_VALUE):
+        new = x.copy()
+        method = _ORTHO_METHODS[x.options.get("orthogonalization", "cgs2")]
+        ip = C.c_double()
+        dep = C.c_int()
+        tab, keep = _ptr_table([q._buf for q in qs]) if len(qs) else (None, None)
+        _lib.call("hipeig_orthonormalize", x.ctx.handle, new._buf.n, len(qs), tab, new._buf.ptr,
+                  float(lindep), method, C.byref(ip), C.byref(dep))
+        return None if dep.value else new
+
+    @staticmethod
+    def solve(H, b, sigma, x0=None, opType="her", reverseGF=False):
+        if not isinstance(H, HipCsrOperator):
+            raise TypeError("HipVector.solve needs a HipCsrOperator (device-resident CSR)")
+        if x0 is not None:
+            raise NotImplementedError("HipVector.solve starts from a zero guess (the Lanczos path passes none)")
+        if isinstance(sigma, complex) or np.iscomplexobj(sigma):
+            raise TypeError("complex shifts belong to the FEAST follow-up")
+        o = b.options["linearSystemArgs"]
+        name = o["linearSolver"]
+        if name != "minres":
+            if name in ("gcrotmk", "pardiso"):
+                raise NotImplementedError(
+                    f"linearSolver={name!r} is not available on the device yet; use 'minres'")
+            raise Exception("Got linear solver other than gcrotmk, minres and pardiso!")
+        out = b.ctx.alloc(b._buf.n)
+        info = C.c_int()
+        stats = (C.c_double * 8)()
+        _lib.call("hipeig_minres", b.ctx.handle, H.handle, float(sigma), -1.0 if reverseGF else 1.0,
+                  b._buf.ptr, out.ptr, float(o["linear_tol"]), int(o["linearIter"]), C.byref(info), stats)
+        res = b._new(out)
+        res.last_solve_stats = {"iterations": int(stats[0]), "istop": int(stats[1]), "rnorm": stats[2],
+                                "Anorm": stats[3], "ynorm": stats[4], "test1": stats[5],
+                                "test2": stats[6], "Acond": stats[7]}
+        b.last_solve_stats = res.last_solve_stats
+        if info.value != 0:
+            # numpyVector.py:175-177: the warning is escalated to an exception
+            raise UserWarning("Warning:: Iterative solver is not converged ")
+        return res
+
+    @staticmethod
+    def _multi_dot(vectors, x):
+        v0 = vectors[0]
+        out = np.empty(len(vectors), dtype=np.float64)
+        tab, keep = _ptr_table([v._buf for v in vectors])
+        _lib.call("hipeig_multi_dot", v0.ctx.handle, v0._buf.n, len(vectors), tab, x._buf.ptr,
+                  out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    @staticmethod
+    def overlapMatrix(vectors):
+        m = len(vectors)
+        v0 = vectors[0]
+        S = np.empty((m, m), dtype=np.float64)
+        tab, keep = _ptr_table([v._buf for v in vectors])
+        _lib.call("hipeig_gram", v0.ctx.handle, v0._buf.n, m, tab, m, tab,
+                  S.ctypes.data_as(C.POINTER(C.c_double)))
+        return np.triu(S) + np.triu(S, 1).T            # upper triangle mirrored, numpyVector.py:199-202
+
+    @staticmethod
+    def matrixRepresentation(operator, vectors):
+        m = len(vectors)
+        M = np.empty((m, m), dtype=np.float64)
+        for j in range(m):
+            ket = vectors[j].applyOp(operator)
+            M[:, j] = HipVector._multi_dot(vectors, ket)
+        return np.tril(M) + np.tril(M, -1).T           # lower triangle mirrored, numpyVector.py:186-189
+
+    @staticmethod
+    def extendOverlapMatrix(vectors, overlap):
+        col = HipVector._multi_dot(vectors, vectors[-1])
+        m = len(vectors)
+        S = np.empty((m, m), dtype=np.float64)
+        S[:m - 1, :m - 1] = overlap
+        S[:, m - 1] = col
+        S[m - 1, :] = col
+        return S
+
+    @staticmethod
+    def extendMatrixRepresentation(operator, vectors, opMat):
+        ket = vectors[-1].applyOp(operator)
+        col = HipVector._multi_dot(vectors, ket)
+        m = len(vectors)
+        M = np.empty((m, m), dtype=np.float64)
+        M[:m - 1, :m - 1] = opMat
+        M[:, m - 1] = col
+        M[m - 1, :] = col
+        return M

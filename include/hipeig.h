@@ -1,0 +1,150 @@
+/*
+ * hipeig.h - C ABI of libhipeig.so: the MI355X (gfx950) backend of the inexact-Lanczos
+ * shift-and-invert hot path.
+ *
+ * This is the drop-in boundary.  The upstream reference has no FFI of its own: its
+ * plugin surface is the Python ABC ``AbstractVector`` (abstractVector.py:15-169) and the
+ * ndarray backend ``NumpyVector`` (numpyVector.py:23-238).  Every entry point below is
+ * what a ``HipVector`` sitting beside ``NumpyVector`` binds through ``ctypes``; each one
+ * cites the reference call site it replaces.  Signatures use plain pointers and sizes
+ * only (no torch / numpy types).  All device pointers are raw ``double*`` obtained from
+ * ``hipeig_vec_alloc``; a "vector" is the LOCAL row slice of the (possibly
+ * row-partitioned) global vector, ``n`` always being the local length.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; ``hipeig_last_error()``
+ *     returns a thread-local human-readable message for the last failure.
+ *   - functions that return scalars to the host (dot, nrm2, gram, minres info ...) are
+ *     synchronous on return; all others are asynchronous on the context's compute
+ *     stream and ordered with respect to each other.
+ *   - reductions use a fixed grid and a fixed summation tree: results are bitwise
+ *     reproducible run to run for the same inputs, device and rank count.
+ *   - with a communicator attached (hipeig_comm_init) every reduction is followed by an
+ *     RCCL all-reduce and every operator application by an all-gather of x.
+ */
+#ifndef HIPEIG_H
+#define HIPEIG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hipeig_ctx hipeig_ctx;   /* device, streams, workspaces, communicator      */
+typedef struct hipeig_csr hipeig_csr;   /* device-resident sparse operator (local rows)    */
+
+/* ---- context ---------------------------------------------------------------------- */
+int hipeig_ctx_create(int device, hipeig_ctx** out);
+int hipeig_ctx_destroy(hipeig_ctx* ctx);
+int hipeig_ctx_sync(hipeig_ctx* ctx);                       /* wait for the compute stream */
+const char* hipeig_last_error(void);
+/* info[0]=CU count, [1]=wave size, [2]=total HBM bytes, [3]=free HBM bytes, [4]=L2 bytes  */
+int hipeig_device_info(hipeig_ctx* ctx, int64_t info[8], char* name, int name_len);
+
+/* ---- communicator (one process per GPU; RCCL over xGMI) --------------------------- */
+/* The host side exchanges the 128-byte id out of band (torch.distributed/gloo, MPI...). */
+int hipeig_comm_unique_id(void* id128);
+int hipeig_comm_init(hipeig_ctx* ctx, int nranks, int rank, const void* id128);
+int hipeig_comm_destroy(hipeig_ctx* ctx);
+int hipeig_comm_info(hipeig_ctx* ctx, int* nranks, int* rank);
+
+/* ---- vectors: replaces the ndarray held by NumpyVector (numpyVector.py:25-28) ----- */
+int hipeig_vec_alloc(hipeig_ctx* ctx, int64_t n, double** out);
+int hipeig_vec_free(hipeig_ctx* ctx, double* v);
+int hipeig_vec_upload(hipeig_ctx* ctx, double* dst, const double* host_src, int64_t n);
+int hipeig_vec_download(hipeig_ctx* ctx, double* host_dst, const double* src, int64_t n);
+int hipeig_vec_copy(hipeig_ctx* ctx, double* dst, const double* src, int64_t n);  /* copy(), :95 */
+int hipeig_vec_fill(hipeig_ctx* ctx, double* v, int64_t n, double value);
+
+/* ---- BLAS-1 class ----------------------------------------------------------------- */
+/* vdot / np.dot, numpyVector.py:89-93 (real vectors: conjugated == bilinear)            */
+int hipeig_dot(hipeig_ctx* ctx, int64_t n, const double* x, const double* y, double* out);
+/* la.norm, numpyVector.py:80-81                                                          */
+int hipeig_nrm2(hipeig_ctx* ctx, int64_t n, const double* x, double* out);
+/* normalize(): x /= ||x||, numpyVector.py:76-78; returns the norm it divided by          */
+int hipeig_normalize(hipeig_ctx* ctx, int64_t n, double* x, double* norm_out);
+/* __mul__/__rmul__/__truediv__ (out of place), numpyVector.py:57-64: y = alpha*x         */
+int hipeig_scale(hipeig_ctx* ctx, int64_t n, double alpha, const double* x, double* y);
+/* y = x / alpha (a true division, as ndarray/alpha rounds)                               */
+int hipeig_divide(hipeig_ctx* ctx, int64_t n, double alpha, const double* x, double* y);
+/* y = a*x + b*y                                                                          */
+int hipeig_axpby(hipeig_ctx* ctx, int64_t n, double a, const double* x, double b, double* y);
+/* linearCombination, numpyVector.py:105-119: out = sum_j coeffs[j]*vecs[j]  (k >= 1)     */
+int hipeig_lincomb(hipeig_ctx* ctx, int64_t n, int k, const double* coeffs,
+                   const double* const* vecs, double* out);
+/* basisTransformation, util_funcs.py:208-231: outs[c] = sum_j C[j*ldc + c]*vecs[j]       */
+int hipeig_lincomb_block(hipeig_ctx* ctx, int64_t n, int m, int k, const double* C, int ldc,
+                         const double* const* vecs, double* const* outs);
+
+/* ---- tall-skinny products --------------------------------------------------------- */
+/* out[j] = <Y_j, x>, j < m : one pass over x and the m basis columns.  Replaces the m
+ * python-level vdots of extendOverlapMatrix / extendMatrixRepresentation
+ * (numpyVector.py:205-238) and the projections of the Gram-Schmidt sweep (:132-139).     */
+int hipeig_multi_dot(hipeig_ctx* ctx, int64_t n, int m, const double* const* Y,
+                     const double* x, double* out);
+/* x += sum_j c[j]*Y_j                                                                    */
+int hipeig_multi_axpy(hipeig_ctx* ctx, int64_t n, int m, const double* const* Y,
+                      const double* c, double* x);
+/* out[i*mb + j] = <A_i, B_j> (row-major ma x mb). overlapMatrix (numpyVector.py:192-203)
+ * with A == B; matrixRepresentation (:180-190) with B = H*A.                             */
+int hipeig_gram(hipeig_ctx* ctx, int64_t n, int ma, const double* const* A, int mb,
+                const double* const* B, double* out);
+/* orthogonalize_against_set, numpyVector.py:121-145.  x is orthogonalised against the m
+ * columns of Y in place and normalised by sqrt(x.x).  method 0 = the reference's single
+ * modified-Gram-Schmidt sweep (division by q.q included), 1 = classical GS applied twice
+ * (two batched passes, one reduction each).  *innerprod receives x.x BEFORE
+ * normalisation; if it is <= lindep x is left un-normalised and *is_lindep = 1 (the
+ * caller returns None, numpyVector.py:141-144).                                          */
+int hipeig_orthonormalize(hipeig_ctx* ctx, int64_t n, int m, const double* const* Y,
+                          double* x, double lindep, int method, double* innerprod,
+                          int* is_lindep);
+
+/* ---- sparse operator: replaces the scipy.sparse / ndarray H handed to the loop ----- */
+/* Host CSR -> device.  rowptr has nrows+1 entries (local rows), col holds GLOBAL column
+ * indices in [0, ncols).  Rows may be empty or unsorted; duplicates are summed by the
+ * product.  row_offset = global index of local row 0 (row partition), used for the fused
+ * shift term sigma*x[row].                                                               */
+int hipeig_csr_create(hipeig_ctx* ctx, int64_t nrows, int64_t ncols, int64_t row_offset,
+                      const int64_t* rowptr, const int32_t* col, const double* val,
+                      hipeig_csr** out);
+/* Seeded synthetic "gapped random-sparse Hermitian" operator generated on the device
+ * (rows [row_begin,row_end) of the N x N matrix); bit-identical to
+ * eigensolvers_amd.generators.gapped_csr_host.  params: see generators.py.               */
+int hipeig_csr_generate(hipeig_ctx* ctx, int64_t N, int64_t row_begin, int64_t row_end,
+                        int K, uint64_t seed, double eps, uint32_t keep_thresh24,
+                        const double* targets, int ntargets, hipeig_csr** out);
+int hipeig_csr_destroy(hipeig_ctx* ctx, hipeig_csr* A);
+/* info[0]=nrows [1]=ncols [2]=nnz [3]=row_offset [4]=kernel variant [5]=device bytes      */
+int hipeig_csr_info(hipeig_csr* A, int64_t info[8]);
+/* copy the device CSR (local rows) back to the host; pass NULL to skip an array          */
+int hipeig_csr_download(hipeig_ctx* ctx, hipeig_csr* A, int64_t* rowptr, int32_t* col,
+                        double* val);
+/* force a kernel variant (0 = automatic choice); for benchmarking/ablation               */
+int hipeig_csr_set_variant(hipeig_csr* A, int variant);
+
+/* applyOp, numpyVector.py:98-100: y = H x.  x,y are local slices.                        */
+int hipeig_spmv(hipeig_ctx* ctx, hipeig_csr* A, const double* x, double* y);
+/* the LinearOperator lambda of solve(), numpyVector.py:152/154:
+ * y = sign*(sigma*x - H x), sign = +1 (Green's function) or -1 (reverseGF)               */
+int hipeig_spmv_shift(hipeig_ctx* ctx, hipeig_csr* A, double sigma, double sign,
+                      const double* x, double* y);
+
+/* ---- inner linear solve: NumpyVector.solve with linearSolver="minres" (:147-178) ---- */
+/* Solves sign*(sigma*I - H) x = b from a zero initial guess with the Paige-Saunders
+ * MINRES recurrences in the evaluation order of scipy.sparse.linalg.minres (the call at
+ * numpyVector.py:163), all vectors and recurrence scalars device-resident.
+ * out_stats: [0]=iterations [1]=istop (SciPy's code) [2]=rnorm estimate [3]=Anorm
+ *            [4]=ynorm [5]=test1 [6]=test2 [7]=Acond.
+ * *info follows SciPy: maxiter if the iteration limit was hit (istop==6) else 0.         */
+int hipeig_minres(hipeig_ctx* ctx, hipeig_csr* A, double sigma, double sign, const double* b,
+                  double* x, double rtol, int maxiter, int* info, double out_stats[8]);
+
+/* ---- timing on the library's compute stream (HIP events) --------------------------- */
+int hipeig_timer_start(hipeig_ctx* ctx);
+int hipeig_timer_stop(hipeig_ctx* ctx, float* elapsed_ms);   /* synchronous */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPEIG_H */

@@ -1,0 +1,309 @@
+"""GPU parity tests: every HIP entry point, called through the C ABI (ctypes binding /
+HipVector), against the CPU oracle and the golden vectors of the real reference.
+
+Tolerances (fp64 path, stated per test): element-wise kernels 1e-15..1e-14 relative;
+reductions 1e-13 relative to sum|a_i b_i|; inner solves 1e-9 relative to ||x||; Ritz values
+1e-10 relative (the north-star bound); iteration counts equal."""
+import ctypes as C
+import warnings
+
+import numpy as np
+import pytest
+import scipy.linalg as la
+import scipy.sparse as sp
+
+from conftest import load_golden
+from eigensolvers_amd.generators import dense_test_matrix, gapped_csr_host, guess_vector
+from oracle import lanczos_ref
+from oracle.minres_ref import minres as minres_ref
+from oracle.numpy_vector import RefVector
+
+pytestmark = pytest.mark.gpu
+
+
+def _opts(it=2000, tol=1e-10, **extra):
+    d = {"linearSystemArgs": {"linearSolver": "minres", "linearIter": it, "linear_tol": tol}}
+    d.update(extra)
+    return d
+
+
+# ---------------------------------------------------------------- BLAS-1 class
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 1000, 4097, 1 << 20, (1 << 21) + 3])
+def test_blas1_against_numpy(hip, n):
+    rng = np.random.default_rng(n)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    X, Y = hip.HipVector(x), hip.HipVector(y)
+    scale = np.sum(np.abs(x * y)) + 1e-300
+    assert abs(X.vdot(Y) - np.dot(x, y)) <= 1e-13 * scale
+    assert abs(X.vdot(Y, conjugate=False) - np.dot(x, y)) <= 1e-13 * scale
+    assert abs(X.norm() - np.linalg.norm(x)) <= 1e-14 * np.linalg.norm(x)
+    np.testing.assert_array_equal((X * 1.7).array, x * 1.7)              # one rounding: exact
+    np.testing.assert_array_equal((-0.3 * X).array, x * -0.3)
+    np.testing.assert_array_equal((X / 3.0).array, x / 3.0)              # true division: exact
+    assert len(X) == n and X.dtype == np.float64 and X.maxD == 0 and X.hasExactAddition
+    Z = X.copy()
+    Z.normalize()
+    np.testing.assert_allclose(Z.array, x / np.linalg.norm(x), rtol=4e-16, atol=0)
+    np.testing.assert_array_equal(X.array, x)                            # copy() did not alias
+    with pytest.raises(NotImplementedError):
+        X *= 2.0
+    with pytest.raises(NotImplementedError):
+        X /= 2.0
+
+
+@pytest.mark.parametrize("n,m", [(5, 1), (1001, 3), (4096, 7), (100003, 17), (1 << 18, 40)])
+def test_tall_skinny_against_numpy(hip, n, m):
+    rng = np.random.default_rng(n + m)
+    Yh = rng.standard_normal((n, m))
+    x = rng.standard_normal(n)
+    V = [hip.HipVector(Yh[:, j].copy()) for j in range(m)]
+    X = hip.HipVector(x)
+    got = hip.HipVector._multi_dot(V, X)
+    ref = Yh.T @ x
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-13 * np.abs(Yh).T @ np.abs(x))
+    c = rng.standard_normal(m)
+    lc = hip.HipVector.linearCombination(V, c)
+    np.testing.assert_allclose(lc.array, Yh @ c, rtol=0, atol=1e-14 * (np.abs(Yh) @ np.abs(c)) + 1e-300)
+    S = hip.HipVector.overlapMatrix(V)
+    np.testing.assert_allclose(S, Yh.T @ Yh, rtol=0, atol=1e-12 * n)
+    assert np.array_equal(S, S.T)
+    # block combination (basisTransformation with a matrix)
+    Cm = rng.standard_normal((m, 3))
+    outs = hip.basisTransformation(V, Cm)
+    for k in range(3):
+        np.testing.assert_allclose(outs[k].array, Yh @ Cm[:, k], rtol=0, atol=1e-13 * (np.abs(Yh) @ np.abs(Cm[:, k])))
+
+
+def test_vector_ops_match_reference_golden(hip, gapped4000):
+    Hh, _ = gapped4000
+    N = 4000
+    H = hip.HipCsrOperator.from_scipy(Hh)
+    g = load_golden("spmv_n4000.npz")
+    x = np.random.default_rng(11).standard_normal(N)
+    row_scale = np.abs(Hh) @ np.abs(x)
+    for variant in (1, 2):
+        H.set_variant(variant)
+        np.testing.assert_allclose(hip.HipVector(x).applyOp(H).array, g["y"], rtol=0, atol=1e-14 * row_scale)
+        y = hip.HipContext.default().alloc(N)
+        H.apply_shifted(0.02, hip.HipVector(x)._buf, y)
+        np.testing.assert_allclose(hip.HipVector(y).array, g["yshift"], rtol=0, atol=1e-14 * (row_scale + 0.02 * abs(x)))
+        H.apply_shifted(0.02, hip.HipVector(x)._buf, y, reverse=True)
+        np.testing.assert_allclose(hip.HipVector(y).array, -g["yshift"], rtol=0, atol=1e-14 * (row_scale + 0.02 * abs(x)))
+    H.set_variant(0)
+    rng = np.random.default_rng(21)
+    Yq = la.qr(rng.standard_normal((N, 7)), mode="economic")[0]
+    xv = rng.standard_normal(N)
+    m = load_golden("mgs_step.npz")
+    for method, tol in (("mgs", 1e-13), ("cgs2", 1e-12)):
+        qs = [hip.HipVector(Yq[:, i].copy(), {"orthogonalization": method}) for i in range(7)]
+        out = hip.HipVector.orthogonalize_against_set(hip.HipVector(xv.copy(), {"orthogonalization": method}), qs)
+        np.testing.assert_allclose(out.array, m["out"], rtol=0, atol=tol)
+        assert np.max(np.abs(Yq.T @ out.array)) < 1e-14 if method == "cgs2" else True
+        dep = hip.HipVector(Yq[:, :3] @ np.array([0.3, -0.2, 0.9]), {"orthogonalization": method})
+        assert hip.HipVector.orthogonalize_against_set(dep, qs) is None and bool(m["dep_is_none"])
+    vecs = [hip.HipVector(rng.standard_normal(N)) for _ in range(5)]
+    gm = load_golden("gram_n4000.npz")
+    np.testing.assert_allclose(hip.HipVector.overlapMatrix(vecs), gm["S"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(hip.HipVector.matrixRepresentation(H, vecs), gm["Hm"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(hip.HipVector.extendOverlapMatrix(vecs, hip.HipVector.overlapMatrix(vecs[:4])),
+                               gm["Sext"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(hip.HipVector.extendMatrixRepresentation(H, vecs, hip.HipVector.matrixRepresentation(H, vecs[:4])),
+                               gm["Hext"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(hip.HipVector.linearCombination(vecs, [0.5, -1.25, 2.0, 0.125, -3.0]).array,
+                               gm["lincomb"], rtol=0, atol=1e-14)
+
+
+# ---------------------------------------------------------------- operator edge cases
+def test_spmv_ragged_empty_long_and_unsorted_rows(hip):
+    rng = np.random.default_rng(5)
+    n = 3000
+    rows = []
+    for i in range(n):
+        if i % 7 == 0:
+            k = 0                                   # empty rows
+        elif i == 11:
+            k = 2600                                # longer than one LDS tile (2048)
+        elif i == 1500:
+            k = n                                   # dense row
+        else:
+            k = int(rng.integers(1, 90))
+        cols = rng.integers(0, n, size=k)           # unsorted, duplicates allowed
+        rows.append((cols, rng.standard_normal(k)))
+    rowptr = np.concatenate([[0], np.cumsum([len(c) for c, _ in rows])]).astype(np.int64)
+    col = np.concatenate([c for c, _ in rows]).astype(np.int32)
+    val = np.concatenate([v for _, v in rows])
+    A = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+    x = rng.standard_normal(n)
+    ref = A @ x
+    scale = np.abs(A) @ np.abs(x) + 1e-300
+    H = hip.HipCsrOperator.from_csr_arrays(rowptr, col, val, n)
+    for variant in (1, 2):
+        H.set_variant(variant)
+        got = hip.HipVector(x).applyOp(H).array
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-14 * scale)
+        assert np.all(got[::7] == 0.0)
+    # rectangular slab (rows 100..900 of the same matrix): what one rank of a partition holds
+    slab = hip.HipCsrOperator.from_scipy(A, 100, 900)
+    assert slab.shape == (800, n) and slab.row_offset == 100
+    # degenerate shapes
+    E = hip.HipCsrOperator.from_csr_arrays(np.zeros(5, dtype=np.int64), np.zeros(0, np.int32), np.zeros(0), 4)
+    np.testing.assert_array_equal(hip.HipVector(np.ones(4)).applyOp(E).array, np.zeros(4))
+    with pytest.raises(Exception):
+        hip.HipCsrOperator.from_csr_arrays(np.array([0, 1]), np.array([7], np.int32), np.ones(1), 4)   # col out of range
+    with pytest.raises(TypeError):
+        hip.HipVector(x).applyOp(A)                 # a host matrix is not a device operator
+
+
+def test_device_generator_is_bit_identical_to_host(hip):
+    for N, nnz_row, seed in ((4000, 32, 7), (3001, 64, 11), (70001, 16, 3)):
+        Hd = hip.HipCsrOperator.generate(N, nnz_row, seed=seed).to_scipy()
+        Hh = gapped_csr_host(N, nnz_row, seed=seed)
+        assert np.array_equal(Hd.indptr, Hh.indptr) and np.array_equal(Hd.indices, Hh.indices)
+        assert np.array_equal(Hd.data, Hh.data)
+    part = hip.HipCsrOperator.generate(4000, 32, seed=7, row_begin=1234, row_end=3210).to_scipy()
+    assert abs(part - gapped_csr_host(4000, 32, seed=7)[1234:3210]).max() == 0.0
+
+
+# ---------------------------------------------------------------- inner solve
+@pytest.mark.parametrize("rtol,maxiter", [(1e-10, 2000), (1e-4, 2000), (1e-6, 2000)])
+def test_minres_tracks_the_oracle(hip, gapped4000, rtol, maxiter):
+    Hh, guess = gapped4000
+    H = hip.HipCsrOperator.from_scipy(Hh)
+    b = guess / np.linalg.norm(guess)
+    trace = []
+    xo, info, itn, istop = minres_ref(lambda v: 0.02 * v - Hh @ v, b, rtol=rtol, maxiter=maxiter, trace=trace)
+    B = hip.HipVector(b.copy(), _opts(maxiter, rtol))
+    W = hip.HipVector.solve(H, B, 0.02)
+    st = W.last_solve_stats
+    assert st["iterations"] == itn and st["istop"] == istop
+    np.testing.assert_allclose(W.array, xo, rtol=0, atol=1e-9 * np.linalg.norm(xo))
+    assert abs(st["rnorm"] - trace[-1]["rnorm"]) <= 1e-6 * trace[-1]["rnorm"]
+    assert abs(st["Anorm"] - trace[-1]["Anorm"]) <= 1e-10 * trace[-1]["Anorm"]
+    # reverse Green's function: (H - sigma) x = b  ->  x = -w
+    Wr = hip.HipVector.solve(H, B, 0.02, reverseGF=True)
+    np.testing.assert_allclose(Wr.array, -xo, rtol=0, atol=1e-9 * np.linalg.norm(xo))
+    # true residual of the returned solution
+    r = b - (0.02 * W.array - Hh @ W.array)
+    assert np.linalg.norm(r) <= 50 * rtol * np.linalg.norm(Hh @ W.array - 0.02 * W.array) + 1e-12
+
+
+def test_solve_matches_reference_golden_and_error_behaviour(hip, gapped4000):
+    Hh, guess = gapped4000
+    H = hip.HipCsrOperator.from_scipy(Hh)
+    g = load_golden("solve_n4000_minres.npz")
+    b = guess / np.linalg.norm(guess)
+    W = hip.HipVector.solve(H, hip.HipVector(b.copy(), _opts()), 0.02)
+    np.testing.assert_allclose(W.array, g["w"], rtol=0, atol=1e-9 * float(g["wnorm"]))
+    with pytest.raises(UserWarning):                              # numpyVector.py:175-177
+        hip.HipVector.solve(H, hip.HipVector(b.copy(), _opts(5, 1e-12)), 0.02)
+    with pytest.raises(NotImplementedError):
+        hip.HipVector.solve(H, hip.HipVector(b.copy(), {"linearSystemArgs": {"linearSolver": "gcrotmk"}}), 0.02)
+    with pytest.raises(Exception):
+        hip.HipVector.solve(H, hip.HipVector(b.copy(), {"linearSystemArgs": {"linearSolver": "bogus"}}), 0.02)
+    zero = hip.HipVector.solve(H, hip.HipVector(np.zeros(4000), _opts()), 0.02)
+    assert np.all(zero.array == 0.0)                              # beta1 == 0 exit of MINRES
+    opts = {}
+    hip.HipVector(b.copy(), opts)
+    assert opts == {}                                             # defaults go into linearSystemArgs only if given
+    lsa = {"linearSystemArgs": {}}
+    hip.HipVector(b.copy(), lsa)
+    assert lsa["linearSystemArgs"] == {"linearSolver": "minres", "linearIter": 1000, "linear_tol": 1e-4,
+                                       "linear_atol": 1e-4}      # numpyVector.py:31-36
+
+
+# ---------------------------------------------------------------- the full path
+def test_lanczos_single_vector_matches_reference(hip, gapped4000):
+    Hh, guess = gapped4000
+    g = load_golden("gapped_csr_n4000_minres.npz")
+    for src in ("upload", "generate"):
+        H = hip.HipCsrOperator.from_scipy(Hh) if src == "upload" else hip.HipCsrOperator.generate(4000, 32, seed=7)
+        for method in ("cgs2", "mgs"):
+            v0 = hip.HipVector(guess.copy(), _opts(orthogonalization=method))
+            ev, Y, st = hip.inexactLanczosDiagonalization(H, v0, 0.02, 8, 10, 1e-13, writeOut=False)
+            assert abs(ev[0] - g["ev"][0]) <= 1e-10 * abs(g["ev"][0])        # north-star tolerance
+            assert st["cumIter"] == int(g["cumIter"]) and st["isConverged"]
+            assert isinstance(ev, np.ndarray) and isinstance(Y, list) and isinstance(Y[0], hip.HipVector)
+            ov = abs(np.dot(Y[0].array, g["vec0"]))
+            assert abs(ov - 1) < 1e-8
+            S = hip.HipVector.overlapMatrix(Y)
+            np.testing.assert_allclose(S, np.eye(len(Y)), atol=1e-7)
+            res = hip.true_residual_norms(H, ev, Y, 1)
+            assert res[0] < 1e-8
+
+
+def test_lanczos_dense_reference_test_case(hip):
+    """unittests/test_lanczos.py restated for HipVector (the dense matrix stored as full CSR,
+    MINRES as inner solver since GCROT is not on the device yet)."""
+    g = load_golden("lanczos_n100_seed1212.npz")
+    A, exact = dense_test_matrix(100, 1212)
+    H = hip.HipCsrOperator.from_dense(A)
+    ev, Y, st = hip.inexactLanczosDiagonalization(H, hip.HipVector(g["guess"].copy(), _opts(1000, 1e-4)),
+                                                  30, 6, 4, 1e-6, writeOut=False)
+    evo, Yo, sto = lanczos_ref.inexact_lanczos(A, RefVector(g["guess"].copy(), _opts(1000, 1e-4)), 30, 6, 4, 1e-6)
+    assert st["cumIter"] == sto["cumIter"] and st["isConverged"] == sto["isConverged"]
+    np.testing.assert_allclose(ev[0], evo[0], rtol=1e-8)
+    assert abs(hip.find_nearest(ev, 30)[1] - hip.find_nearest(exact, 30)[1]) <= 1e-4
+    S = hip.HipVector.overlapMatrix(Y)
+    np.testing.assert_allclose(S, np.eye(len(Y)), atol=1e-5)
+    S1 = hip.HipVector.overlapMatrix(Y[:-1])
+    np.testing.assert_allclose(hip.HipVector.extendOverlapMatrix(Y, S1), S, atol=1e-9)
+    w, V = np.linalg.eigh(A)
+    vec = Y[hip.find_nearest(ev, 30)[0]].array
+    ov = np.vdot(V[:, hip.find_nearest(w, 30)[0]], vec)
+    np.testing.assert_allclose(abs(ov), 1, rtol=1e-5)
+
+
+def test_lanczos_block_and_lindep_exit_match_reference(hip, gapped4000):
+    Hh, _ = gapped4000
+    H = hip.HipCsrOperator.from_scipy(Hh)
+    for nb, L, maxit, tol, econv, tag in ((3, 3, 12, 1e-8, 1e-7, "block3"), (4, 3, 12, 1e-10, 1e-7, "block4_lindep")):
+        g = load_golden(f"gapped_csr_n4000_{tag}.npz")
+        Q = la.qr(np.random.default_rng(5).standard_normal((4000, nb)), mode="economic")[0]
+        v0 = [hip.HipVector(Q[:, i].copy(), _opts(2000, tol, orthogonalization="mgs")) for i in range(nb)]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ev, Y, st = hip.inexactLanczosDiagonalization(H, v0, 0.02, L, maxit, econv, writeOut=False)
+        if tag == "block3":
+            np.testing.assert_allclose(np.sort(ev[:nb]), np.sort(g["ev"][:nb]), rtol=1e-6)   # eConv = 1e-7 run
+            assert st["isConverged"] and st["cumIter"] == int(g["cumIter"])
+        else:
+            assert np.all(np.isnan(ev)) and not st["isConverged"]
+            assert st["cumIter"] == int(g["cumIter"]) and len(Y) == int(g["nvec"])
+    bad = [hip.HipVector(np.ones(4000), _opts()), hip.HipVector(np.ones(4000), _opts())]
+    with pytest.raises(RuntimeError):
+        hip.inexactLanczosDiagonalization(H, bad, 0.02, 3, 1, 1e-6, writeOut=False)
+
+
+# ---------------------------------------------------------------- full-size properties
+def test_full_size_operator_properties(hip):
+    """N = 1e6, nnz/row = 32 (BASELINE config #2 shape): size-independent properties -
+    symmetry <x,Hy> = <Hx,y>, linearity, agreement of the two kernel variants, the shifted
+    form, and a slab generated separately equals the same rows of the full operator."""
+    N = 1_000_000
+    H = hip.HipCsrOperator.generate(N, 32, seed=7)
+    assert abs(H.nnz / N - 33) < 0.1
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(N), rng.standard_normal(N)
+    X, Y = hip.HipVector(x), hip.HipVector(y)
+    HX, HY = X.applyOp(H), Y.applyOp(H)
+    a, b = X.vdot(HY), HX.vdot(Y)
+    assert abs(a - b) <= 1e-12 * (abs(a) + np.sqrt(N))
+    Z = hip.HipVector.linearCombination([X, Y], [2.0, -3.0])
+    lhs = Z.applyOp(H)
+    rhs = hip.HipVector.linearCombination([HX, HY], [2.0, -3.0])
+    d = hip.HipVector.linearCombination([lhs, rhs], [1.0, -1.0])
+    assert d.norm() <= 1e-14 * rhs.norm() * 10
+    H.set_variant(1)
+    hv = X.applyOp(H)
+    d = hip.HipVector.linearCombination([hv, HX], [1.0, -1.0])
+    assert d.norm() <= 1e-14 * HX.norm()
+    H.set_variant(0)
+    # rows 400000..400500 against the host generator's slab
+    slab = gapped_csr_host(N, 32, seed=7, row_begin=400000, row_end=400500)
+    np.testing.assert_allclose(HX.array[400000:400500], slab @ x, rtol=0, atol=1e-13 * (np.abs(slab) @ np.abs(x)))
+    buf = hip.HipContext.default().alloc(N)
+    H.apply_shifted(0.02, X._buf, buf)
+    s = hip.HipVector(buf)
+    t = hip.HipVector.linearCombination([X, HX], [0.02, -1.0])
+    d = hip.HipVector.linearCombination([s, t], [1.0, -1.0])
+    assert d.norm() <= 1e-15 * t.norm() * 10
