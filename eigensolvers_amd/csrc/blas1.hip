@@ -366,8 +366,8 @@ mgs_update_kernel(int64_t n, const double* __restrict__ t, const double* __restr
   const double coef = t[0] / t[1];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const double proj = __dmul_rn(q[i], coef);
-    x[i] = __dadd_rn(x[i], -proj);
+    const double proj = mul_rn(q[i], coef);
+    x[i] = add_rn(x[i], -proj);
   }
 }
 

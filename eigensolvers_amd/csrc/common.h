@@ -80,7 +80,14 @@ struct hipeig_csr {
   double* d_val;             // nnz
   int32_t* d_row_blocks;     // n_row_blocks+1 row indices: block b owns rows [rb[b], rb[b+1])
   int32_t n_row_blocks;
-  int variant;               // 0 = auto, 1 = CSR-vector, 2 = CSR-stream (LDS-staged)
+  // column-window blocked copy (see spmv_device.h, "TCOO"); built on first use
+  uint32_t* t_idx;
+  double* t_val;
+  uint32_t* t_off;
+  int32_t t_nunits, t_nwin, t_wbits, t_rw;
+  int64_t gather_len;        // length of the gathered operand (ncols, or stride*nranks)
+  int variant;               // 0 = auto, 1 = CSR-vector, 2 = CSR-stream (LDS-staged), 3 = TCOO
+  int last_variant;          // variant used by the most recent launch (0 = none yet)
   int lanes_per_row;         // sub-wave width used to reduce one row
   int64_t col_stride;        // x_full stride per rank when columns were remapped (0 = global)
   int64_t bytes;
@@ -93,6 +100,18 @@ int hipeig_allgather_x(hipeig_ctx* ctx, const double* x_local, int64_t n_local,
                        const double** x_full_out);
 
 // ---- device helpers ------------------------------------------------------------------
+// Separately rounded multiply / add.  hipcc contracts a*b+c into an FMA by default and the
+// __dmul_rn/__dadd_rn intrinsics are plain operators in ROCm, so an explicit pragma is the
+// only way to keep two roundings where the reference's NumPy expression has two.
+__host__ __device__ __forceinline__ double mul_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__host__ __device__ __forceinline__ double add_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+
 __device__ __forceinline__ double wave_reduce_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

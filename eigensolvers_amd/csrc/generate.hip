@@ -68,7 +68,7 @@ __device__ __forceinline__ double gen_value(uint64_t s, uint64_t valkey, double 
   const uint64_t h = mix64(s ^ valkey);
   const int64_t sum = (int64_t)(h & 0xFFFF) + (int64_t)((h >> 16) & 0xFFFF) +
                       (int64_t)((h >> 32) & 0xFFFF) + (int64_t)(h >> 48);
-  return __dmul_rn((double)(sum - 131070), vscale);
+  return mul_rn((double)(sum - 131070), vscale);
 }
 
 __device__ __forceinline__ double gen_diag(int64_t i, const GenParams& P, const double* targets) {
@@ -76,8 +76,8 @@ __device__ __forceinline__ double gen_diag(int64_t i, const GenParams& P, const 
     const int64_t t = (i - P.target_first) / P.target_stride;
     if (t < P.ntargets) return targets[t];
   }
-  const double u = __dmul_rn((double)(mix64((uint64_t)i ^ P.diagkey) >> 11), 1.1102230246251565e-16);  // 2^-53
-  const double mag = __dadd_rn(1.0, __dmul_rn(9.0, u));
+  const double u = mul_rn((double)(mix64((uint64_t)i ^ P.diagkey) >> 11), 1.1102230246251565e-16);  // 2^-53
+  const double mag = add_rn(1.0, mul_rn(9.0, u));
   return (mix64((uint64_t)i ^ P.signkey) & 1ULL) ? -mag : mag;
 }
 

@@ -16,7 +16,10 @@
 #include "spmv_device.h"
 
 CsrView hipeig_csr_view(const hipeig_csr* A);
+TcooView hipeig_tcoo_view(const hipeig_csr* A);
 int hipeig_spmv_grid(const hipeig_csr* A, int variant);
+int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A);
+size_t hipeig_tcoo_lds_bytes(const hipeig_csr* A);
 
 #define MR_EPS 2.220446049250313e-16
 
@@ -65,7 +68,7 @@ struct MinresRowEpilogue {
   double* __restrict__ y;
   __device__ __forceinline__ void row(int64_t r, double sum, double& acc) const {
     const double v = s * r2l[r];
-    double yv = sign * (__dmul_rn(sigma, v) - s * sum);
+    double yv = sign * (mul_rn(sigma, v) - s * sum);
     if (use_r1) yv -= c1 * r1[r];
     y[r] = yv;
     acc = fma(v, yv, acc);
@@ -74,11 +77,12 @@ struct MinresRowEpilogue {
 
 template <int VARIANT>
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
-minres_ka_kernel(CsrView A, const double* __restrict__ xg, MinresArgs a, const MinresState* __restrict__ Sin,
+minres_ka_kernel(CsrView A, TcooView T, const double* __restrict__ xg, MinresArgs a, const MinresState* __restrict__ Sin,
                  MinresState* __restrict__ Sout, const double* __restrict__ r2l,
                  const double* __restrict__ r1, double* __restrict__ y, double* __restrict__ partials) {
   __shared__ double prod[VARIANT == 2 ? SPMV_NNZ_PER_BLOCK : 8];
   __shared__ double red[4];
+  extern __shared__ double tcoo_lds[];
   MinresState S = *Sin;
   const double xx = (S.itn > 0 && !S.done) ? sum_or_value(a.pD, a.nD, red) : 0.0;
   minres_tests(S, xx, a);
@@ -90,7 +94,8 @@ minres_ka_kernel(CsrView A, const double* __restrict__ xg, MinresArgs a, const M
   epi.c1 = epi.use_r1 ? S.beta / S.oldb : 0.0;
   epi.r2l = r2l; epi.r1 = r1; epi.y = y;
   double acc = 0.0;
-  if (VARIANT == 2) csr_stream_sweep(A, xg, epi, acc, prod);
+  if (VARIANT == 3) tcoo_sweep(T, xg, epi, acc, tcoo_lds);
+  else if (VARIANT == 2) csr_stream_sweep(A, xg, epi, acc, prod);
   else csr_vector_sweep(A, xg, epi, acc);
   acc = block_reduce_sum(acc, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = acc;
@@ -248,8 +253,13 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   MinresState* V = c->d_mr_state;
   HIPEIG_CHECK(hipMemcpyAsync(V, h, sizeof(MinresState), hipMemcpyHostToDevice, c->stream));
 
-  const int variant = A->variant ? A->variant : 2;
+  const int variant = hipeig_csr_pick_variant(c, A);
+  if (variant < 0) return 1;
   const CsrView view = hipeig_csr_view(A);
+  const TcooView tview = hipeig_tcoo_view(A);
+  if (variant == 3)
+    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)hipeig_tcoo_lds_bytes(A)));
   const int gA = hipeig_spmv_grid(A, variant);
   const int gE = grid_for(n, 4);
   double* pA = c->d_partials;
@@ -276,10 +286,12 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
       double* w2 = W[(k + 2) % 3];
       const double* xg = nullptr;
       if (hipeig_allgather_x(c, r2, n, &xg)) return 4;
-      if (variant == 1)
-        hipLaunchKernelGGL((minres_ka_kernel<1>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream, view, xg, a, V + 0, V + 1, r2, r1, yb, pA);
+      if (variant == 3)
+        hipLaunchKernelGGL((minres_ka_kernel<3>), dim3(gA), dim3(HIPEIG_BLOCK), hipeig_tcoo_lds_bytes(A), c->stream, view, tview, xg, a, V + 0, V + 1, r2, r1, yb, pA);
+      else if (variant == 1)
+        hipLaunchKernelGGL((minres_ka_kernel<1>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream, view, tview, xg, a, V + 0, V + 1, r2, r1, yb, pA);
       else
-        hipLaunchKernelGGL((minres_ka_kernel<2>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream, view, xg, a, V + 0, V + 1, r2, r1, yb, pA);
+        hipLaunchKernelGGL((minres_ka_kernel<2>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream, view, tview, xg, a, V + 0, V + 1, r2, r1, yb, pA);
       if (dist) {
         hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pA, gA, red + 0);
         if (hipeig_allreduce_sum(c, red + 0, 1)) return 4;

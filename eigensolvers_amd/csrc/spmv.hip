@@ -3,6 +3,9 @@
 #include <vector>
 #include "spmv_device.h"
 
+int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A);
+size_t hipeig_tcoo_lds_bytes(const hipeig_csr* A);
+
 // y[r] = a_self*xl[r] + a_sum*sum  (a_self = 0, a_sum = 1: plain product;
 // a_self = sign*sigma, a_sum = -sign: the shifted operator of numpyVector.py:152/154).
 // Two roundings like the reference's sigma*x - H@x (no contraction into an FMA).
@@ -11,8 +14,8 @@ struct AxpyEpilogue {
   const double* __restrict__ xl;
   double* __restrict__ y;
   __device__ __forceinline__ void row(int64_t r, double sum, double& acc) const {
-    const double t = (a_self == 0.0) ? 0.0 : __dmul_rn(a_self, xl[r]);
-    y[r] = __dadd_rn(t, __dmul_rn(a_sum, sum));
+    const double t = (a_self == 0.0) ? 0.0 : mul_rn(a_self, xl[r]);
+    y[r] = add_rn(t, mul_rn(a_sum, sum));
   }
 };
 
@@ -29,6 +32,21 @@ spmv_vector_kernel(CsrView A, const double* __restrict__ x, AxpyEpilogue epi) {
   csr_vector_sweep(A, x, epi, acc);
 }
 
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+spmv_tcoo_kernel(TcooView T, const double* __restrict__ x, AxpyEpilogue epi) {
+  extern __shared__ double tcoo_lds[];
+  double acc = 0.0;
+  tcoo_sweep(T, x, epi, acc, tcoo_lds);
+}
+
+TcooView hipeig_tcoo_view(const hipeig_csr* A) {
+  TcooView t;
+  t.idx = A->t_idx; t.val = A->t_val; t.off = A->t_off;
+  t.nunits = A->t_nunits; t.nwin = A->t_nwin; t.wbits = A->t_wbits; t.rw = A->t_rw;
+  t.nrows = A->nrows;
+  return t;
+}
+
 CsrView hipeig_csr_view(const hipeig_csr* A) {
   CsrView v;
   v.rowptr = A->d_rowptr;
@@ -43,7 +61,9 @@ CsrView hipeig_csr_view(const hipeig_csr* A) {
 
 int hipeig_spmv_grid(const hipeig_csr* A, int variant) {
   int64_t g;
-  if (variant == 1) {
+  if (variant == 3) {
+    g = (A->t_nunits + 3) / 4;                       // 4 waves (units in flight) per workgroup
+  } else if (variant == 1) {
     const int64_t groups_per_block = HIPEIG_BLOCK / A->lanes_per_row;
     g = (A->nrows + groups_per_block - 1) / groups_per_block;
   } else {
@@ -60,10 +80,14 @@ static int launch_spmv(hipeig_ctx* c, hipeig_csr* A, double a_self, double a_sum
   const double* xg = nullptr;
   if (hipeig_allgather_x(c, x, A->nrows, &xg)) return 4;
   AxpyEpilogue epi{a_self, a_sum, x, y};
-  const int variant = A->variant ? A->variant : 2;
+  const int variant = hipeig_csr_pick_variant(c, A);
+  if (variant < 0) return 1;
   const CsrView v = hipeig_csr_view(A);
   const int g = hipeig_spmv_grid(A, variant);
-  if (variant == 1)
+  if (variant == 3)
+    hipLaunchKernelGGL(spmv_tcoo_kernel, dim3(g), dim3(HIPEIG_BLOCK), hipeig_tcoo_lds_bytes(A), c->stream,
+                       hipeig_tcoo_view(A), xg, epi);
+  else if (variant == 1)
     hipLaunchKernelGGL(spmv_vector_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, v, xg, epi);
   else
     hipLaunchKernelGGL(spmv_stream_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, v, xg, epi);
@@ -81,6 +105,128 @@ extern "C" int hipeig_spmv_shift(hipeig_ctx* c, hipeig_csr* A, double sigma, dou
   HIPEIG_REQUIRE(x != y, "in-place product is not supported");
   HIPEIG_REQUIRE(sign == 1.0 || sign == -1.0, "sign must be +1 or -1");
   return launch_spmv(c, A, sign * sigma, -sign, x, y);
+}
+
+// ---- TCOO construction -------------------------------------------------------------------
+// One workgroup per unit (RW consecutive rows), rows handled in chunks of 256 (one row per
+// thread).  count pass: non-zeros per (unit, window).  fill pass: a non-zero of row r and
+// window c goes to  off[unit][c] + (#nnz of window c in earlier rows of the unit) + (#earlier
+// nnz of window c in row r): row-major order inside every tile, independent of scheduling.
+#define TCOO_MAX_WIN 128
+
+__global__ void __launch_bounds__(256)
+tcoo_build_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                  const double* __restrict__ val, int64_t nrows, int rw, int nwin, int wbits,
+                  uint32_t* __restrict__ counts /* [nunits][nwin], count pass */,
+                  const uint32_t* __restrict__ off /* fill pass */, uint32_t* __restrict__ t_idx,
+                  double* __restrict__ t_val, int fill) {
+  extern __shared__ uint32_t tb_lds[];               // cnt[256][nwin] then base[nwin]
+  uint32_t* cnt = tb_lds;
+  uint32_t* base = tb_lds + 256 * nwin;
+  const int u = blockIdx.x, t = threadIdx.x;
+  for (int c = t; c < nwin; c += 256) base[c] = fill ? off[(size_t)u * nwin + c] : 0u;
+  const int64_t row0 = (int64_t)u * rw;
+  for (int chunk = 0; chunk < rw; chunk += 256) {
+    const int64_t r = row0 + chunk + t;
+    const bool live = (chunk + t < rw) && (r < nrows);
+    for (int c = 0; c < nwin; ++c) cnt[t * nwin + c] = 0;
+    int s = 0, e = 0;
+    if (live) {
+      s = rowptr[r]; e = rowptr[r + 1];
+      for (int p = s; p < e; ++p) cnt[t * nwin + (col[p] >> wbits)] += 1;
+    }
+    __syncthreads();
+    // column-wise exclusive scan over the 256 rows of the chunk (thread c scans window c)
+    for (int c = t; c < nwin; c += 256) {
+      uint32_t run = base[c];
+      for (int k = 0; k < 256; ++k) {
+        const uint32_t v = cnt[k * nwin + c];
+        cnt[k * nwin + c] = run;
+        run += v;
+      }
+      base[c] = run;
+    }
+    __syncthreads();
+    if (fill && live) {
+      const uint32_t rl = (uint32_t)(chunk + t);
+      for (int p = s; p < e; ++p) {
+        const int cc = col[p];
+        const int c = cc >> wbits;
+        const uint32_t dst = cnt[t * nwin + c]++;
+        t_idx[dst] = (rl << wbits) | ((uint32_t)cc & ((1u << wbits) - 1u));
+        t_val[dst] = val[p];
+      }
+    }
+    __syncthreads();
+  }
+  if (!fill)
+    for (int c = t; c < nwin; c += 256) counts[(size_t)u * nwin + c] = base[c];
+}
+
+size_t hipeig_tcoo_lds_bytes(const hipeig_csr* A) { return (size_t)4 * A->t_rw * sizeof(double); }
+
+// Build the column-window blocked copy (idempotent).  Returns 0 on success, 1 on failure,
+// 2 if the operator does not suit the layout (caller falls back to the CSR-stream kernel).
+int hipeig_csr_build_tcoo(hipeig_ctx* c, hipeig_csr* A) {
+  if (A->t_idx) return 0;
+  if (A->nnz == 0 || A->nrows == 0) return 2;
+  int wbits = TCOO_MAX_WBITS;
+  while (wbits > 10 && ((int64_t)1 << (wbits - 1)) >= A->gather_len) --wbits;   // one window if x is short
+  const int nwin = (int)((A->gather_len + ((int64_t)1 << wbits) - 1) >> wbits);
+  if (nwin > TCOO_MAX_WIN) return 2;
+  // rows per wave: fill 2 workgroups x 4 waves per CU, at most TCOO_MAX_RW (20 KiB LDS per wave)
+  int64_t rw = (A->nrows + (int64_t)c->num_cu * 8 - 1) / ((int64_t)c->num_cu * 8);
+  rw = (rw + 63) / 64 * 64;
+  if (rw < 64) rw = 64;
+  if (rw > TCOO_MAX_RW) rw = TCOO_MAX_RW;
+  if (rw > ((int64_t)1 << (32 - wbits))) rw = (int64_t)1 << (32 - wbits);
+  const int nunits = (int)((A->nrows + rw - 1) / rw);
+  uint32_t* d_counts = nullptr;
+  const size_t ntile = (size_t)nunits * nwin;
+  HIPEIG_CHECK(hipMalloc((void**)&d_counts, ntile * sizeof(uint32_t)));
+  const size_t lds = ((size_t)256 * nwin + nwin) * sizeof(uint32_t);
+  HIPEIG_CHECK(hipFuncSetAttribute((const void*)tcoo_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(tcoo_build_kernel, dim3(nunits), dim3(256), lds, c->stream, A->d_rowptr, A->d_col, A->d_val,
+                     A->nrows, (int)rw, nwin, wbits, d_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                     (double*)nullptr, 0);
+  HIPEIG_CHECK(hipGetLastError());
+  std::vector<uint32_t> off(ntile + 1);
+  HIPEIG_CHECK(hipMemcpyAsync(off.data() + 1, d_counts, ntile * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  off[0] = 0;
+  uint64_t run = 0;
+  for (size_t i = 1; i <= ntile; ++i) { run += off[i]; off[i] = (uint32_t)run; }
+  HIPEIG_REQUIRE(run == (uint64_t)A->nnz, "TCOO count pass lost non-zeros");
+  HIPEIG_CHECK(hipFree(d_counts));
+  HIPEIG_CHECK(hipMalloc((void**)&A->t_off, (ntile + 1) * sizeof(uint32_t)));
+  HIPEIG_CHECK(hipMalloc((void**)&A->t_idx, (size_t)A->nnz * sizeof(uint32_t)));
+  HIPEIG_CHECK(hipMalloc((void**)&A->t_val, (size_t)A->nnz * sizeof(double)));
+  HIPEIG_CHECK(hipMemcpyAsync(A->t_off, off.data(), (ntile + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(tcoo_build_kernel, dim3(nunits), dim3(256), lds, c->stream, A->d_rowptr, A->d_col, A->d_val,
+                     A->nrows, (int)rw, nwin, wbits, (uint32_t*)nullptr, (const uint32_t*)A->t_off, A->t_idx, A->t_val, 1);
+  HIPEIG_CHECK(hipGetLastError());
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  A->t_nunits = nunits; A->t_nwin = nwin; A->t_wbits = wbits; A->t_rw = (int)rw;
+  HIPEIG_CHECK(hipFuncSetAttribute((const void*)spmv_tcoo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)hipeig_tcoo_lds_bytes(A)));
+  A->bytes += (int64_t)A->nnz * 12 + (int64_t)(ntile + 1) * 4;
+  return 0;
+}
+
+// The variant a launch will use (building the TCOO copy on demand); -1 on failure.
+int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A) {
+  int variant = A->variant;
+  if (variant == 0) {
+    // the gathered operand does not fit one XCD's L2 -> window it; small problems stream
+    variant = (A->gather_len * 8 > (int64_t)3 << 20 && A->nnz > (int64_t)1 << 20) ? 3 : 2;
+  }
+  if (variant == 3) {
+    const int rc = hipeig_csr_build_tcoo(c, A);
+    if (rc == 1) return -1;
+    if (rc == 2) variant = 2;
+  }
+  A->last_variant = variant;
+  return variant;
 }
 
 // ---- layout preparation ------------------------------------------------------------------
@@ -119,6 +265,7 @@ int hipeig_csr_finalize(hipeig_ctx* c, hipeig_csr* A, const int32_t* rowptr32) {
   A->lanes_per_row = mean < 6 ? 4 : mean < 24 ? 8 : mean < 96 ? 16 : mean < 384 ? 32 : 64;
   A->bytes = (A->nrows + 1) * 4 + A->nnz * 12 + (int64_t)rb.size() * 4;
 
+  A->gather_len = A->ncols;
   // distributed: gather row counts, size x_full and remap global columns to its layout
   int64_t stride = 0;
   if (hipeig_comm_setup_rows(c, A->nrows, &stride)) return 4;
@@ -138,6 +285,7 @@ int hipeig_csr_finalize(hipeig_ctx* c, hipeig_csr* A, const int32_t* rowptr32) {
     }
     HIPEIG_CHECK(hipStreamSynchronize(c->stream));
     A->col_stride = stride;
+    A->gather_len = stride * c->nranks;
   }
   return 0;
 }
@@ -182,18 +330,21 @@ extern "C" int hipeig_csr_destroy(hipeig_ctx* c, hipeig_csr* A) {
   if (A->d_col) hipFree(A->d_col);
   if (A->d_val) hipFree(A->d_val);
   if (A->d_row_blocks) hipFree(A->d_row_blocks);
+  if (A->t_idx) hipFree(A->t_idx);
+  if (A->t_val) hipFree(A->t_val);
+  if (A->t_off) hipFree(A->t_off);
   free(A);
   return 0;
 }
 
 extern "C" int hipeig_csr_info(hipeig_csr* A, int64_t info[8]) {
   info[0] = A->nrows; info[1] = A->ncols; info[2] = A->nnz; info[3] = A->row_offset;
-  info[4] = A->variant; info[5] = A->bytes; info[6] = A->n_row_blocks; info[7] = A->lanes_per_row;
+  info[4] = A->last_variant; info[5] = A->bytes; info[6] = A->n_row_blocks; info[7] = A->lanes_per_row;
   return 0;
 }
 
 extern "C" int hipeig_csr_set_variant(hipeig_csr* A, int variant) {
-  HIPEIG_REQUIRE(variant >= 0 && variant <= 2, "unknown variant");
+  HIPEIG_REQUIRE(variant >= 0 && variant <= 3, "unknown variant");
   A->variant = variant;
   return 0;
 }

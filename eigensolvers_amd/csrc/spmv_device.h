@@ -106,3 +106,70 @@ __device__ __forceinline__ void csr_vector_sweep(const CsrView& A, const double*
     if (glane == 0) epi.row(r, sum, acc);
   }
 }
+
+// ---- column-window blocked layout ("TCOO") ----------------------------------------------
+// Random columns make every x gather a separate L2 request, and beyond the 4 MiB L2 of an
+// XCD each one costs a full 128-byte fabric fetch (measured: 57 Ggather/s from an 80 MB
+// table against 215 Ggather/s from an L2-resident one, tools/gather_bench*.hip).  This
+// layout makes the gathers L2-resident: the columns are cut into windows of W = 2^wbits
+// (<= 256 Ki columns = 2 MiB of x), the rows into units of RW rows owned by ONE wavefront,
+// and the non-zeros of a unit are stored window by window, each as a packed 32-bit
+// (row_local << wbits | col_local) plus the fp64 value - 12 bytes per non-zero like CSR.
+// A wave keeps its unit's RW partial sums in LDS, sweeps the windows in order (all waves do,
+// so the chip works on one x window at a time) and scatter-adds v*x into LDS with ds_add_f64.
+// No inter-wave communication at all; adds to one row come from one wave in stream order,
+// so the summation order is fixed and results are reproducible.
+#define TCOO_MAX_WBITS 18
+#define TCOO_MAX_RW 2560                 // 20 KiB of LDS per wave, 8 waves per CU
+#define TCOO_UNROLL 8
+
+struct TcooView {
+  const uint32_t* __restrict__ idx;
+  const double* __restrict__ val;
+  const uint32_t* __restrict__ off;      // nunits*nwin + 1 offsets, unit-major
+  int32_t nunits, nwin, wbits, rw;
+  int64_t nrows;
+};
+
+__device__ __forceinline__ void lds_add_f64(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+template <class Epi>
+__device__ __forceinline__ void tcoo_sweep(const TcooView& T, const double* __restrict__ x, const Epi& epi,
+                                           double& acc, double* lds /* blockDim/64 * rw doubles */) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int waves_per_block = blockDim.x >> 6;
+  double* yacc = lds + (size_t)wid * T.rw;
+  const uint32_t cmask = (1u << T.wbits) - 1u;
+  const int nwaves = gridDim.x * waves_per_block;
+  for (int u = blockIdx.x * waves_per_block + wid; u < T.nunits; u += nwaves) {
+    for (int k = lane; k < T.rw; k += 64) yacc[k] = 0.0;
+    const uint32_t* offu = T.off + (size_t)u * T.nwin;
+    for (int c = 0; c < T.nwin; ++c) {
+      const uint32_t beg = offu[c], end = offu[c + 1];
+      const double* __restrict__ xw = x + ((size_t)c << T.wbits);
+      uint32_t p = beg + lane;
+      for (; p + 64 * (TCOO_UNROLL - 1) < end; p += 64 * TCOO_UNROLL) {
+        uint32_t id[TCOO_UNROLL];
+        double v[TCOO_UNROLL];
+#pragma unroll
+        for (int j = 0; j < TCOO_UNROLL; ++j) {
+          id[j] = __builtin_nontemporal_load(T.idx + p + 64 * j);
+          v[j] = __builtin_nontemporal_load(T.val + p + 64 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < TCOO_UNROLL; ++j) v[j] *= xw[id[j] & cmask];
+#pragma unroll
+        for (int j = 0; j < TCOO_UNROLL; ++j) lds_add_f64(yacc + (id[j] >> T.wbits), v[j]);
+      }
+      for (; p < end; p += 64) {
+        const uint32_t id = __builtin_nontemporal_load(T.idx + p);
+        const double v = __builtin_nontemporal_load(T.val + p);
+        lds_add_f64(yacc + (id >> T.wbits), v * xw[id & cmask]);
+      }
+    }
+    const int64_t r0 = (int64_t)u * T.rw;
+    for (int k = lane; k < T.rw && r0 + k < T.nrows; k += 64) epi.row(r0 + k, yacc[k], acc);
+  }
+}

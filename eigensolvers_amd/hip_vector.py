@@ -181,8 +181,16 @@ class HipCsrOperator:
                   t.ctypes.data_as(C.POINTER(C.c_double)), len(t), C.byref(h))
         return cls(ctx, h)
 
+    VARIANTS = {0: "none", 1: "csr-vector", 2: "csr-stream", 3: "column-window-blocked"}
+
     def set_variant(self, variant):
         _lib.call("hipeig_csr_set_variant", self.handle, int(variant))
+
+    def last_variant(self):
+        """Name of the kernel variant the most recent product used."""
+        info = (C.c_int64 * 8)()
+        _lib.call("hipeig_csr_info", self.handle, info)
+        return self.VARIANTS[int(info[4])]
 
     def to_scipy(self):
         import scipy.sparse as sp

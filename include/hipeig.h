@@ -115,12 +115,13 @@ int hipeig_csr_generate(hipeig_ctx* ctx, int64_t N, int64_t row_begin, int64_t r
                         int K, uint64_t seed, double eps, uint32_t keep_thresh24,
                         const double* targets, int ntargets, hipeig_csr** out);
 int hipeig_csr_destroy(hipeig_ctx* ctx, hipeig_csr* A);
-/* info[0]=nrows [1]=ncols [2]=nnz [3]=row_offset [4]=kernel variant [5]=device bytes      */
+/* info[0]=nrows [1]=ncols [2]=nnz [3]=row_offset [4]=kernel variant of the last launch
+ * (1 CSR-vector, 2 CSR-stream, 3 column-window blocked) [5]=device bytes [6]=row blocks   */
 int hipeig_csr_info(hipeig_csr* A, int64_t info[8]);
 /* copy the device CSR (local rows) back to the host; pass NULL to skip an array          */
 int hipeig_csr_download(hipeig_ctx* ctx, hipeig_csr* A, int64_t* rowptr, int32_t* col,
                         double* val);
-/* force a kernel variant (0 = automatic choice); for benchmarking/ablation               */
+/* force a kernel variant (0 = automatic choice, 1..3 as above); for benchmarking/ablation */
 int hipeig_csr_set_variant(hipeig_csr* A, int variant);
 
 /* applyOp, numpyVector.py:98-100: y = H x.  x,y are local slices.                        */
