@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--nnz-row", type=int, default=64)
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--sigma", type=float, default=0.02)
-    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 CSR-vector, 2 CSR-stream, 3 column-window blocked")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 CSR-vector, 2 CSR-stream, 3/4 column-window blocked (wave / workgroup units)")
     ap.add_argument("--no-lanczos", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--lanczos-L", type=int, default=3)
@@ -128,7 +128,8 @@ def main():
                    "kernel_variant": ("auto:" if a.variant == 0 else "forced:") + H.last_variant(),
                    "generator_seed": a.seed, "generate_s": round(t_gen, 2)},
         "roofline": {"bound": "hbm", "kernel": {"csr-vector": "spmv_vector_kernel", "csr-stream": "spmv_stream_kernel",
-                                                  "column-window-blocked": "spmv_tcoo_kernel"}[H.last_variant()],
+                                                  "column-window-blocked(wave)": "spmv_tcoo_kernel",
+                                                  "column-window-blocked(workgroup)": "spmv_tcoow_kernel"}[H.last_variant()],
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": int(H.algorithmic_bytes()),

@@ -84,9 +84,14 @@ struct hipeig_csr {
   uint32_t* t_idx;
   double* t_val;
   uint32_t* t_off;
-  int32_t t_nunits, t_nwin, t_wbits, t_rw;
+  int32_t t_nunits, t_nwin, t_wbits, t_rw, t_wgs_per_sweep, t_prefetch;
+  // workgroup-wide column-bucketed copy ("TCOO-W", variant 4); built on first use
+  uint32_t* w_idx;
+  double* w_val;
+  uint32_t* w_off;
+  int32_t w_nunits, w_nwin, w_wbits, w_rw, w_wgs_per_sweep;
   int64_t gather_len;        // length of the gathered operand (ncols, or stride*nranks)
-  int variant;               // 0 = auto, 1 = CSR-vector, 2 = CSR-stream (LDS-staged), 3 = TCOO
+  int variant;               // 0 = auto, 1 = CSR-vector, 2 = CSR-stream, 3 = TCOO (wave units), 4 = TCOO-W
   int last_variant;          // variant used by the most recent launch (0 = none yet)
   int lanes_per_row;         // sub-wave width used to reduce one row
   int64_t col_stride;        // x_full stride per rank when columns were remapped (0 = global)

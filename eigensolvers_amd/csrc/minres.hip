@@ -17,6 +17,8 @@
 
 CsrView hipeig_csr_view(const hipeig_csr* A);
 TcooView hipeig_tcoo_view(const hipeig_csr* A);
+TcooView hipeig_tcoow_view(const hipeig_csr* A);
+size_t hipeig_tcoow_lds_bytes(const hipeig_csr* A);
 int hipeig_spmv_grid(const hipeig_csr* A, int variant);
 int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A);
 size_t hipeig_tcoo_lds_bytes(const hipeig_csr* A);
@@ -76,12 +78,12 @@ struct MinresRowEpilogue {
 };
 
 template <int VARIANT>
-__global__ void __launch_bounds__(HIPEIG_BLOCK)
+__global__ void __launch_bounds__(VARIANT == 4 ? TCOOW_THREADS : HIPEIG_BLOCK)
 minres_ka_kernel(CsrView A, TcooView T, const double* __restrict__ xg, MinresArgs a, const MinresState* __restrict__ Sin,
                  MinresState* __restrict__ Sout, const double* __restrict__ r2l,
                  const double* __restrict__ r1, double* __restrict__ y, double* __restrict__ partials) {
   __shared__ double prod[VARIANT == 2 ? SPMV_NNZ_PER_BLOCK : 8];
-  __shared__ double red[4];
+  __shared__ double red[16];
   extern __shared__ double tcoo_lds[];
   MinresState S = *Sin;
   const double xx = (S.itn > 0 && !S.done) ? sum_or_value(a.pD, a.nD, red) : 0.0;
@@ -94,11 +96,12 @@ minres_ka_kernel(CsrView A, TcooView T, const double* __restrict__ xg, MinresArg
   epi.c1 = epi.use_r1 ? S.beta / S.oldb : 0.0;
   epi.r2l = r2l; epi.r1 = r1; epi.y = y;
   double acc = 0.0;
-  if (VARIANT == 3) tcoo_sweep(T, xg, epi, acc, tcoo_lds);
+  if (VARIANT == 4) tcoo_wg_sweep(T, xg, epi, acc, tcoo_lds);
+  else if (VARIANT == 3) tcoo_sweep(T, xg, epi, acc, tcoo_lds);
   else if (VARIANT == 2) csr_stream_sweep(A, xg, epi, acc, prod);
   else csr_vector_sweep(A, xg, epi, acc);
   acc = block_reduce_sum(acc, red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;      // the host offsets `partials` per sweep
 }
 
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
@@ -256,7 +259,10 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   const int variant = hipeig_csr_pick_variant(c, A);
   if (variant < 0) return 1;
   const CsrView view = hipeig_csr_view(A);
-  const TcooView tview = hipeig_tcoo_view(A);
+  const TcooView tview = (variant == 4) ? hipeig_tcoow_view(A) : hipeig_tcoo_view(A);
+  if (variant == 4)
+    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)hipeig_tcoow_lds_bytes(A)));
   if (variant == 3)
     HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)hipeig_tcoo_lds_bytes(A)));
@@ -269,7 +275,10 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   double* red = c->d_scalars + 2048;    // reduced sums for the distributed path
   MinresArgs a;
   a.sigma = sigma; a.sign = sign; a.rtol = rtol; a.maxiter = maxiter;
-  a.pA = dist ? red + 0 : pA; a.nA = dist ? 1 : gA;
+  const int nsweepA = (variant == 4) ? (A->w_nunits + gA - 1) / gA
+                    : (variant == 3) ? (A->t_nunits + gA * 4 - 1) / (gA * 4) : 1;
+  HIPEIG_REQUIRE(nsweepA * gA <= HIPEIG_MAX_PARTIALS, "too many sweeps for the partial-sum buffer");
+  a.pA = dist ? red + 0 : pA; a.nA = dist ? 1 : gA * nsweepA;
   a.pC = dist ? red + 1 : pC; a.nC = dist ? 1 : gE;
   a.pD = dist ? red + 2 : pD; a.nD = dist ? 1 : gE;
 
@@ -286,14 +295,24 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
       double* w2 = W[(k + 2) % 3];
       const double* xg = nullptr;
       if (hipeig_allgather_x(c, r2, n, &xg)) return 4;
-      if (variant == 3)
-        hipLaunchKernelGGL((minres_ka_kernel<3>), dim3(gA), dim3(HIPEIG_BLOCK), hipeig_tcoo_lds_bytes(A), c->stream, view, tview, xg, a, V + 0, V + 1, r2, r1, yb, pA);
-      else if (variant == 1)
+      if (variant == 4) {
+        TcooView tv = tview;
+        for (int sw = 0; sw < nsweepA; ++sw) {
+          tv.unit_begin = sw * gA;
+          hipLaunchKernelGGL((minres_ka_kernel<4>), dim3(gA), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, view, tv, xg, a, V + 0, V + 1, r2, r1, yb, pA + sw * gA);
+        }
+      } else if (variant == 3) {
+        TcooView tv = tview;
+        for (int sw = 0; sw < nsweepA; ++sw) {       // one launch per sweep; partials side by side
+          tv.unit_begin = sw * gA * 4;
+          hipLaunchKernelGGL((minres_ka_kernel<3>), dim3(gA), dim3(HIPEIG_BLOCK), hipeig_tcoo_lds_bytes(A), c->stream, view, tv, xg, a, V + 0, V + 1, r2, r1, yb, pA + sw * gA);
+        }
+      } else if (variant == 1)
         hipLaunchKernelGGL((minres_ka_kernel<1>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream, view, tview, xg, a, V + 0, V + 1, r2, r1, yb, pA);
       else
         hipLaunchKernelGGL((minres_ka_kernel<2>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream, view, tview, xg, a, V + 0, V + 1, r2, r1, yb, pA);
       if (dist) {
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pA, gA, red + 0);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pA, gA * nsweepA, red + 0);
         if (hipeig_allreduce_sum(c, red + 0, 1)) return 4;
       }
       hipLaunchKernelGGL(minres_kc_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 1, V + 2, r2, yb, pC);

@@ -5,6 +5,7 @@
 
 int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A);
 size_t hipeig_tcoo_lds_bytes(const hipeig_csr* A);
+size_t hipeig_tcoow_lds_bytes(const hipeig_csr* A);
 
 // y[r] = a_self*xl[r] + a_sum*sum  (a_self = 0, a_sum = 1: plain product;
 // a_self = sign*sigma, a_sum = -sign: the shifted operator of numpyVector.py:152/154).
@@ -39,11 +40,36 @@ spmv_tcoo_kernel(TcooView T, const double* __restrict__ x, AxpyEpilogue epi) {
   tcoo_sweep(T, x, epi, acc, tcoo_lds);
 }
 
+__global__ void __launch_bounds__(TCOOW_THREADS)
+spmv_tcoow_kernel(TcooView T, const double* __restrict__ x, AxpyEpilogue epi) {
+  extern __shared__ double tcoo_lds[];
+  double acc = 0.0;
+  tcoo_wg_sweep(T, x, epi, acc, tcoo_lds);
+}
+
+TcooView hipeig_tcoow_view(const hipeig_csr* A) {
+  TcooView t;
+  t.idx = A->w_idx; t.val = A->w_val; t.off = A->w_off;
+  t.nunits = A->w_nunits; t.nwin = A->w_nwin; t.wbits = A->w_wbits; t.rw = A->w_rw;
+  t.unit_begin = 0;
+  t.prefetch = 0;
+  t.ablate = 0;
+  if (const char* e = getenv("HIPEIG_TCOO_ABLATE")) t.ablate = atoi(e);   // timing experiments (wrong results)
+  t.nrows = A->nrows;
+  t.gather_len = A->gather_len;
+  return t;
+}
+
 TcooView hipeig_tcoo_view(const hipeig_csr* A) {
   TcooView t;
   t.idx = A->t_idx; t.val = A->t_val; t.off = A->t_off;
   t.nunits = A->t_nunits; t.nwin = A->t_nwin; t.wbits = A->t_wbits; t.rw = A->t_rw;
+  t.unit_begin = 0;
+  t.prefetch = A->t_prefetch;
+  t.ablate = 0;
+  if (const char* e = getenv("HIPEIG_TCOO_ABLATE")) t.ablate = atoi(e);   // timing experiments (wrong results)
   t.nrows = A->nrows;
+  t.gather_len = A->gather_len;
   return t;
 }
 
@@ -61,8 +87,13 @@ CsrView hipeig_csr_view(const hipeig_csr* A) {
 
 int hipeig_spmv_grid(const hipeig_csr* A, int variant) {
   int64_t g;
-  if (variant == 3) {
-    g = (A->t_nunits + 3) / 4;                       // 4 waves (units in flight) per workgroup
+  if (variant == 4) {
+    g = A->w_wgs_per_sweep;                          // one unit per workgroup, one workgroup per CU
+    if (g > A->w_nunits) g = A->w_nunits;
+  } else if (variant == 3) {
+    g = A->t_wgs_per_sweep;                          // workgroups of ONE sweep (4 units each)
+    const int64_t need = (A->t_nunits + 3) / 4;
+    if (g > need) g = need;
   } else if (variant == 1) {
     const int64_t groups_per_block = HIPEIG_BLOCK / A->lanes_per_row;
     g = (A->nrows + groups_per_block - 1) / groups_per_block;
@@ -84,10 +115,19 @@ static int launch_spmv(hipeig_ctx* c, hipeig_csr* A, double a_self, double a_sum
   if (variant < 0) return 1;
   const CsrView v = hipeig_csr_view(A);
   const int g = hipeig_spmv_grid(A, variant);
-  if (variant == 3)
-    hipLaunchKernelGGL(spmv_tcoo_kernel, dim3(g), dim3(HIPEIG_BLOCK), hipeig_tcoo_lds_bytes(A), c->stream,
-                       hipeig_tcoo_view(A), xg, epi);
-  else if (variant == 1)
+  if (variant == 4) {
+    TcooView t = hipeig_tcoow_view(A);
+    for (int ub = 0; ub < A->w_nunits; ub += g) {                // one launch per sweep
+      t.unit_begin = ub;
+      hipLaunchKernelGGL(spmv_tcoow_kernel, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t, xg, epi);
+    }
+  } else if (variant == 3) {
+    TcooView t = hipeig_tcoo_view(A);
+    for (int ub = 0; ub < A->t_nunits; ub += g * 4) {            // one launch per sweep
+      t.unit_begin = ub;
+      hipLaunchKernelGGL(spmv_tcoo_kernel, dim3(g), dim3(HIPEIG_BLOCK), hipeig_tcoo_lds_bytes(A), c->stream, t, xg, epi);
+    }
+  } else if (variant == 1)
     hipLaunchKernelGGL(spmv_vector_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, v, xg, epi);
   else
     hipLaunchKernelGGL(spmv_stream_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, v, xg, epi);
@@ -171,6 +211,8 @@ int hipeig_csr_build_tcoo(hipeig_ctx* c, hipeig_csr* A) {
   if (A->t_idx) return 0;
   if (A->nnz == 0 || A->nrows == 0) return 2;
   int wbits = TCOO_MAX_WBITS;
+  if (const char* e = getenv("HIPEIG_TCOO_WBITS")) wbits = atoi(e);          // tuning knob
+  HIPEIG_REQUIRE(wbits >= 10 && wbits <= 22, "HIPEIG_TCOO_WBITS out of range");
   while (wbits > 10 && ((int64_t)1 << (wbits - 1)) >= A->gather_len) --wbits;   // one window if x is short
   const int nwin = (int)((A->gather_len + ((int64_t)1 << wbits) - 1) >> wbits);
   if (nwin > TCOO_MAX_WIN) return 2;
@@ -179,6 +221,8 @@ int hipeig_csr_build_tcoo(hipeig_ctx* c, hipeig_csr* A) {
   rw = (rw + 63) / 64 * 64;
   if (rw < 64) rw = 64;
   if (rw > TCOO_MAX_RW) rw = TCOO_MAX_RW;
+  if (const char* e = getenv("HIPEIG_TCOO_RW")) rw = (atoi(e) + 63) / 64 * 64;   // tuning knob
+  HIPEIG_REQUIRE(rw >= 64 && rw * 32 <= 163840, "HIPEIG_TCOO_RW out of range");
   if (rw > ((int64_t)1 << (32 - wbits))) rw = (int64_t)1 << (32 - wbits);
   const int nunits = (int)((A->nrows + rw - 1) / rw);
   uint32_t* d_counts = nullptr;
@@ -207,8 +251,116 @@ int hipeig_csr_build_tcoo(hipeig_ctx* c, hipeig_csr* A) {
   HIPEIG_CHECK(hipGetLastError());
   HIPEIG_CHECK(hipStreamSynchronize(c->stream));
   A->t_nunits = nunits; A->t_nwin = nwin; A->t_wbits = wbits; A->t_rw = (int)rw;
+  {
+    int per_cu = (int)(163840 / ((size_t)4 * rw * sizeof(double)));           // LDS-limited residency
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    if (const char* e = getenv("HIPEIG_TCOO_WG_PER_CU")) per_cu = atoi(e);    // tuning knob
+    HIPEIG_REQUIRE(per_cu >= 1 && per_cu <= 8, "HIPEIG_TCOO_WG_PER_CU out of range");
+    A->t_wgs_per_sweep = per_cu * c->num_cu;
+    A->t_prefetch = 0;
+    if (const char* e = getenv("HIPEIG_TCOO_PREFETCH")) A->t_prefetch = atoi(e) != 0;   // tuning knob
+  }
   HIPEIG_CHECK(hipFuncSetAttribute((const void*)spmv_tcoo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)hipeig_tcoo_lds_bytes(A)));
+  A->bytes += (int64_t)A->nnz * 12 + (int64_t)(ntile + 1) * 4;
+  return 0;
+}
+
+// ---- TCOO-W construction --------------------------------------------------------------------
+// Bucketing by (unit, column bin) with global counters: count, scan on the host, scatter.
+// Which slot of its bin a non-zero lands in depends on scheduling; the SET of non-zeros of
+// every bin does not, and the kernel's accumulation order is unordered anyway.
+__global__ void __launch_bounds__(256)
+tcoow_bin_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                 const double* __restrict__ val, int64_t nrows, int rw, int binbits, int nbins, int wbits,
+                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ w_idx, double* __restrict__ w_val, int fill) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const uint32_t wmask = (1u << wbits) - 1u;
+  for (int64_t r = wave; r < nrows; r += nwaves) {
+    const int64_t unit = r / rw;
+    const uint32_t rl = (uint32_t)(r - unit * rw);
+    uint32_t* cur = cursor + unit * nbins;
+    const int s = rowptr[r], e = rowptr[r + 1];
+    for (int p = s + lane; p < e; p += 64) {
+      const uint32_t cc = (uint32_t)col[p];
+      const uint32_t slot = atomicAdd(cur + (cc >> binbits), 1u);
+      if (fill) {
+        w_idx[slot] = (rl << wbits) | (cc & wmask);
+        w_val[slot] = val[p];
+      }
+    }
+  }
+}
+
+size_t hipeig_tcoow_lds_bytes(const hipeig_csr* A) {
+  return (size_t)A->w_rw * sizeof(double) + ((size_t)A->w_nwin + 2) * sizeof(uint32_t);
+}
+
+int hipeig_csr_build_tcoow(hipeig_ctx* c, hipeig_csr* A) {
+  if (A->w_idx) return 0;
+  if (A->nnz == 0 || A->nrows == 0) return 2;
+  int wbits = 17;                                      // 15 bits are left for the row inside the unit
+  if (const char* e = getenv("HIPEIG_TCOOW_WBITS")) wbits = atoi(e);         // tuning knob
+  HIPEIG_REQUIRE(wbits >= 10 && wbits <= 17, "HIPEIG_TCOOW_WBITS out of range");
+  while (wbits > 10 && ((int64_t)1 << (wbits - 1)) >= A->gather_len) --wbits;
+  const int nwin = (int)((A->gather_len + ((int64_t)1 << wbits) - 1) >> wbits);
+  if (nwin > 256) return 2;
+  int binbits = 5;                                     // 32 columns = 2 lines of x per bin (measured: 4..6 equal)                                    // 2 Ki columns = 128 lines of x per bin
+  if (const char* e = getenv("HIPEIG_TCOOW_BINBITS")) binbits = atoi(e);     // tuning knob
+  if (binbits > wbits) binbits = wbits;
+  HIPEIG_REQUIRE(binbits >= 4, "HIPEIG_TCOOW_BINBITS out of range");
+  const int bpw = 1 << (wbits - binbits);
+  const int64_t nbins = (int64_t)nwin * bpw;
+  int64_t rw = (A->nrows + c->num_cu - 1) / c->num_cu;                       // one unit per CU if it fits
+  rw = (rw + 63) / 64 * 64;
+  if (rw < 64) rw = 64;
+  if (rw > TCOOW_MAX_RW) rw = TCOOW_MAX_RW;
+  if (const char* e = getenv("HIPEIG_TCOOW_RW")) rw = (atoi(e) + 63) / 64 * 64;   // tuning knob
+  HIPEIG_REQUIRE(rw >= 64 && rw <= TCOOW_MAX_RW && rw <= ((int64_t)1 << (32 - wbits)), "HIPEIG_TCOOW_RW out of range");
+  const int64_t nunits = (A->nrows + rw - 1) / rw;
+  const size_t ncnt = (size_t)(nunits * nbins);
+  HIPEIG_REQUIRE(ncnt < ((size_t)1 << 30), "too many (unit, bin) counters");
+  uint32_t* d_cur = nullptr;
+  HIPEIG_CHECK(hipMalloc((void**)&d_cur, ncnt * sizeof(uint32_t)));
+  HIPEIG_CHECK(hipMemsetAsync(d_cur, 0, ncnt * sizeof(uint32_t), c->stream));
+  const int grid = 8 * c->num_cu;
+  hipLaunchKernelGGL(tcoow_bin_kernel, dim3(grid), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_val, A->nrows,
+                     (int)rw, binbits, (int)nbins, wbits, d_cur, (uint32_t*)nullptr, (double*)nullptr, 0);
+  HIPEIG_CHECK(hipGetLastError());
+  std::vector<uint32_t> cnt(ncnt);
+  HIPEIG_CHECK(hipMemcpyAsync(cnt.data(), d_cur, ncnt * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  const size_t ntile = (size_t)nunits * nwin;
+  std::vector<uint32_t> off(ntile + 1);
+  uint64_t run = 0;
+  for (size_t i = 0; i < ncnt; ++i) {
+    if (i % bpw == 0) off[i / bpw] = (uint32_t)run;
+    const uint32_t n = cnt[i];
+    cnt[i] = (uint32_t)run;                            // exclusive scan in place -> scatter cursors
+    run += n;
+  }
+  off[ntile] = (uint32_t)run;
+  HIPEIG_REQUIRE(run == (uint64_t)A->nnz, "TCOO-W count pass lost non-zeros");
+  HIPEIG_CHECK(hipMemcpyAsync(d_cur, cnt.data(), ncnt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIPEIG_CHECK(hipMalloc((void**)&A->w_off, (ntile + 1) * sizeof(uint32_t)));
+  HIPEIG_CHECK(hipMalloc((void**)&A->w_idx, (size_t)A->nnz * sizeof(uint32_t)));
+  HIPEIG_CHECK(hipMalloc((void**)&A->w_val, (size_t)A->nnz * sizeof(double)));
+  HIPEIG_CHECK(hipMemcpyAsync(A->w_off, off.data(), (ntile + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(tcoow_bin_kernel, dim3(grid), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_val, A->nrows,
+                     (int)rw, binbits, (int)nbins, wbits, d_cur, A->w_idx, A->w_val, 1);
+  HIPEIG_CHECK(hipGetLastError());
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  HIPEIG_CHECK(hipFree(d_cur));
+  A->w_nunits = (int)nunits; A->w_nwin = nwin; A->w_wbits = wbits; A->w_rw = (int)rw;
+  int per_cu = (int)(163840 / (rw * sizeof(double) + ((size_t)nwin + 2) * sizeof(uint32_t) + 256));
+  if (per_cu > 2) per_cu = 2;                          // 1024-thread workgroups: at most 32 waves per CU
+  if (per_cu < 1) per_cu = 1;
+  A->w_wgs_per_sweep = per_cu * c->num_cu;
+  HIPEIG_CHECK(hipFuncSetAttribute((const void*)spmv_tcoow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)hipeig_tcoow_lds_bytes(A)));
   A->bytes += (int64_t)A->nnz * 12 + (int64_t)(ntile + 1) * 4;
   return 0;
 }
@@ -218,7 +370,12 @@ int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A) {
   int variant = A->variant;
   if (variant == 0) {
     // the gathered operand does not fit one XCD's L2 -> window it; small problems stream
-    variant = (A->gather_len * 8 > (int64_t)3 << 20 && A->nnz > (int64_t)1 << 20) ? 3 : 2;
+    variant = (A->gather_len * 8 > (int64_t)3 << 20 && A->nnz > (int64_t)1 << 20) ? 4 : 2;
+  }
+  if (variant == 4) {
+    const int rc = hipeig_csr_build_tcoow(c, A);
+    if (rc == 1) return -1;
+    if (rc == 2) variant = 3;
   }
   if (variant == 3) {
     const int rc = hipeig_csr_build_tcoo(c, A);
@@ -333,6 +490,9 @@ extern "C" int hipeig_csr_destroy(hipeig_ctx* c, hipeig_csr* A) {
   if (A->t_idx) hipFree(A->t_idx);
   if (A->t_val) hipFree(A->t_val);
   if (A->t_off) hipFree(A->t_off);
+  if (A->w_idx) hipFree(A->w_idx);
+  if (A->w_val) hipFree(A->w_val);
+  if (A->w_off) hipFree(A->w_off);
   free(A);
   return 0;
 }
@@ -344,7 +504,7 @@ extern "C" int hipeig_csr_info(hipeig_csr* A, int64_t info[8]) {
 }
 
 extern "C" int hipeig_csr_set_variant(hipeig_csr* A, int variant) {
-  HIPEIG_REQUIRE(variant >= 0 && variant <= 3, "unknown variant");
+  HIPEIG_REQUIRE(variant >= 0 && variant <= 4, "unknown variant");
   A->variant = variant;
   return 0;
 }

@@ -128,11 +128,40 @@ struct TcooView {
   const double* __restrict__ val;
   const uint32_t* __restrict__ off;      // nunits*nwin + 1 offsets, unit-major
   int32_t nunits, nwin, wbits, rw;
-  int64_t nrows;
+  int32_t unit_begin;                    // first unit of this launch (one unit per wave)
+  int32_t prefetch;                      // dense L2 prefetch of the next x window (0/1)
+  int32_t ablate;                        // timing experiments only: 1 = skip gathers, 2 = skip LDS adds
+  int64_t nrows, gather_len;
 };
 
 __device__ __forceinline__ void lds_add_f64(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+// Dense read of this wave's share of an x window (16 B per lane, whole 128-byte lines) so
+// that the window is already in the XCD's L2 when the gathers of the next tile arrive; without
+// it every window switch starts with a storm of cold 8-byte misses, each a full line fetch.
+// Workgroups b and b+8 are observed to share an XCD, so wave (b/8)*wpb + wid of every XCD
+// takes slice number that; a different placement only costs speed, never correctness.
+__device__ __forceinline__ double tcoo_prefetch_window(const double* __restrict__ x, int64_t gather_len,
+                                                       int c, int wbits, int lane, int wid, int wpb) {
+  const int64_t w0 = (int64_t)c << wbits;
+  int64_t wlen = (int64_t)1 << wbits;
+  if (w0 + wlen > gather_len) wlen = gather_len - w0;
+  if (wlen <= 0) return 0.0;
+  const int nslices = ((gridDim.x + 7) / 8) * wpb;
+  const int rank = (blockIdx.x / 8) * wpb + wid;
+  int64_t per = ((wlen + nslices - 1) / nslices + 15) & ~(int64_t)15;     // whole 128-byte lines
+  const int64_t s0 = (int64_t)rank * per;
+  int64_t s1 = s0 + per;
+  if (s1 > wlen) s1 = wlen;
+  double pf = 0.0;
+  const double* base = x + w0;
+  for (int64_t i = s0 + 2 * lane; i + 1 < s1; i += 128) {
+    const double2 t = *reinterpret_cast<const double2*>(base + i);
+    pf += t.x + t.y;
+  }
+  return pf;
 }
 
 template <class Epi>
@@ -142,34 +171,140 @@ __device__ __forceinline__ void tcoo_sweep(const TcooView& T, const double* __re
   const int waves_per_block = blockDim.x >> 6;
   double* yacc = lds + (size_t)wid * T.rw;
   const uint32_t cmask = (1u << T.wbits) - 1u;
-  const int nwaves = gridDim.x * waves_per_block;
-  for (int u = blockIdx.x * waves_per_block + wid; u < T.nunits; u += nwaves) {
+  // One launch = one sweep: every resident wave owns exactly one unit and all of them walk
+  // the windows together; the kernel boundary keeps consecutive sweeps from overlapping
+  // (two sweeps in flight would keep two x windows alive and thrash the L2).
+  const int u = T.unit_begin + blockIdx.x * waves_per_block + wid;
+  double pf = 0.0;
+  if (T.prefetch) pf += tcoo_prefetch_window(x, T.gather_len, 0, T.wbits, lane, wid, waves_per_block);
+  if (u < T.nunits) {
     for (int k = lane; k < T.rw; k += 64) yacc[k] = 0.0;
     const uint32_t* offu = T.off + (size_t)u * T.nwin;
+    uint32_t end = offu[0];
     for (int c = 0; c < T.nwin; ++c) {
-      const uint32_t beg = offu[c], end = offu[c + 1];
+      const uint32_t beg = end;
+      end = offu[c + 1];
+      if (T.prefetch && c + 1 < T.nwin)
+        pf += tcoo_prefetch_window(x, T.gather_len, c + 1, T.wbits, lane, wid, waves_per_block);
       const double* __restrict__ xw = x + ((size_t)c << T.wbits);
-      uint32_t p = beg + lane;
-      for (; p + 64 * (TCOO_UNROLL - 1) < end; p += 64 * TCOO_UNROLL) {
+      // batches of 64*TCOO_UNROLL non-zeros, every slot predicated: no serial tail
+      for (uint32_t base = beg; base < end; base += 64 * TCOO_UNROLL) {
         uint32_t id[TCOO_UNROLL];
         double v[TCOO_UNROLL];
 #pragma unroll
         for (int j = 0; j < TCOO_UNROLL; ++j) {
-          id[j] = __builtin_nontemporal_load(T.idx + p + 64 * j);
-          v[j] = __builtin_nontemporal_load(T.val + p + 64 * j);
+          const uint32_t q = base + lane + 64 * j;
+          const bool ok = q < end;
+          id[j] = ok ? __builtin_nontemporal_load(T.idx + q) : 0xFFFFFFFFu;
+          v[j] = ok ? __builtin_nontemporal_load(T.val + q) : 0.0;
         }
+        if (!(T.ablate & 1)) {
 #pragma unroll
-        for (int j = 0; j < TCOO_UNROLL; ++j) v[j] *= xw[id[j] & cmask];
+          for (int j = 0; j < TCOO_UNROLL; ++j)
+            if (id[j] != 0xFFFFFFFFu) v[j] *= xw[id[j] & cmask];
+        }
+        if (!(T.ablate & 2)) {
 #pragma unroll
-        for (int j = 0; j < TCOO_UNROLL; ++j) lds_add_f64(yacc + (id[j] >> T.wbits), v[j]);
-      }
-      for (; p < end; p += 64) {
-        const uint32_t id = __builtin_nontemporal_load(T.idx + p);
-        const double v = __builtin_nontemporal_load(T.val + p);
-        lds_add_f64(yacc + (id >> T.wbits), v * xw[id & cmask]);
+          for (int j = 0; j < TCOO_UNROLL; ++j)
+            if (id[j] != 0xFFFFFFFFu) lds_add_f64(yacc + (id[j] >> T.wbits), v[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < TCOO_UNROLL; ++j) pf += v[j] + (double)id[j];
+        }
       }
     }
     const int64_t r0 = (int64_t)u * T.rw;
     for (int k = lane; k < T.rw && r0 + k < T.nrows; k += 64) epi.row(r0 + k, yacc[k], acc);
   }
+  asm volatile("" ::"v"(pf));      // keep the prefetch loads alive
+}
+
+// ---- workgroup-wide units ("TCOO-W") ------------------------------------------------------
+// Same storage, but a unit is owned by a whole 512-thread workgroup (one per CU, all 160 KiB
+// of LDS as the y accumulator: up to 20224 rows) and the non-zeros of a tile are bucketed by
+// column (2 Ki-column bins) before being laid out.  The eight waves of the CU then walk the
+// same bins side by side, so lanes that need the same 128-byte line of x meet in one
+// instruction or in the 32 KiB L1: the number of L2 requests per non-zero drops from 1 to
+// about (1 - exp(-k))/k with k = (rows per CU) * (nnz per row) * 16 / ncols lines of reuse
+// (k ~ 2.1 at N = 1e7, 65 nnz/row).  The L2 request rate - not HBM - is what bounds the
+// gather (tools/gather_bench*.hip).  Adds to one row now come from several waves, so the
+// summation ORDER inside a row is not fixed run to run (values agree to rounding).
+#define TCOOW_THREADS 1024
+#define TCOOW_MAX_RW 20224               // 161,792 B of LDS (+ the unit's window offsets)
+
+__device__ __forceinline__ void lds_add_f64_wg(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <class Epi>
+__device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* __restrict__ x, const Epi& epi,
+                                              double& acc, double* yacc /* rw doubles + (nwin+1) uint32 of LDS */) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nw = blockDim.x >> 6;
+  const uint32_t cmask = (1u << T.wbits) - 1u;
+  const int u = T.unit_begin + blockIdx.x;
+  if (u >= T.nunits) return;                         // uniform for the workgroup
+  uint32_t* offL = reinterpret_cast<uint32_t*>(yacc + T.rw);     // this unit's window offsets
+  for (int k = threadIdx.x; k < T.rw; k += blockDim.x) yacc[k] = 0.0;
+  for (int k = threadIdx.x; k <= T.nwin; k += blockDim.x) offL[k] = T.off[(size_t)u * T.nwin + k];
+  __syncthreads();
+  // The unit's non-zeros are ONE contiguous stream (window after window).  Waves take
+  // batches of 64*TCOO_UNROLL round-robin; each lane tracks the window of its elements by
+  // walking the offsets (they only move forward), so a batch may straddle windows and the
+  // stream loads of batch k+1 are in flight while batch k gathers and scatters.
+  const uint32_t uend = offL[T.nwin];
+  const uint32_t step = (uint32_t)nw * 64 * TCOO_UNROLL;
+  uint32_t base = offL[0] + (uint32_t)wid * 64 * TCOO_UNROLL;
+  int c = 0;
+  double sink = 0.0;
+  uint32_t idA[TCOO_UNROLL], idB[TCOO_UNROLL];
+  double vA[TCOO_UNROLL], vB[TCOO_UNROLL];
+#define TCOO_LOAD(ID, V, BASE)                                                         \
+  _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j) {                            \
+    const uint32_t q = (BASE) + lane + 64 * j;                                         \
+    const bool ok = q < uend;                                                          \
+    ID[j] = ok ? __builtin_nontemporal_load(T.idx + q) : 0xFFFFFFFFu;                  \
+    V[j] = ok ? __builtin_nontemporal_load(T.val + q) : 0.0;                           \
+  }
+#define TCOO_CONSUME(ID, V, BASE)                                                      \
+  {                                                                                    \
+    int cw[TCOO_UNROLL];                                                               \
+    _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j) {                          \
+      const uint32_t q = (BASE) + lane + 64 * j;                                       \
+      while (c + 1 < T.nwin && q >= offL[c + 1]) ++c;                                  \
+      cw[j] = c;                                                                       \
+    }                                                                                  \
+    if (!(T.ablate & 1)) {                                                             \
+      _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j)                          \
+        if (ID[j] != 0xFFFFFFFFu) V[j] *= x[((size_t)cw[j] << T.wbits) + (ID[j] & cmask)]; \
+    }                                                                                  \
+    if (!(T.ablate & 2)) {                                                             \
+      _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j)                          \
+        if (ID[j] != 0xFFFFFFFFu) lds_add_f64_wg(yacc + (ID[j] >> T.wbits), V[j]);     \
+    } else {                                                                           \
+      _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j) sink += V[j] + (double)ID[j]; \
+    }                                                                                  \
+  }
+  if (base < uend) {
+    TCOO_LOAD(idA, vA, base)
+    while (true) {
+      const uint32_t nb = base + step;
+      const bool more = nb < uend;                   // uniform per wave
+      if (more) { TCOO_LOAD(idB, vB, nb) }
+      TCOO_CONSUME(idA, vA, base)
+      if (!more) break;
+      const uint32_t nb2 = nb + step;
+      const bool more2 = nb2 < uend;
+      if (more2) { TCOO_LOAD(idA, vA, nb2) }
+      TCOO_CONSUME(idB, vB, nb)
+      if (!more2) break;
+      base = nb2;
+    }
+  }
+#undef TCOO_LOAD
+#undef TCOO_CONSUME
+  asm volatile("" ::"v"(sink));
+  __syncthreads();
+  const int64_t r0 = (int64_t)u * T.rw;
+  for (int k = threadIdx.x; k < T.rw && r0 + k < T.nrows; k += blockDim.x) epi.row(r0 + k, yacc[k], acc);
 }

@@ -181,7 +181,8 @@ class HipCsrOperator:
                   t.ctypes.data_as(C.POINTER(C.c_double)), len(t), C.byref(h))
         return cls(ctx, h)
 
-    VARIANTS = {0: "none", 1: "csr-vector", 2: "csr-stream", 3: "column-window-blocked"}
+    VARIANTS = {0: "none", 1: "csr-vector", 2: "csr-stream", 3: "column-window-blocked(wave)",
+                4: "column-window-blocked(workgroup)"}
 
     def set_variant(self, variant):
         _lib.call("hipeig_csr_set_variant", self.handle, int(variant))

@@ -89,7 +89,7 @@ def test_vector_ops_match_reference_golden(hip, gapped4000):
     g = load_golden("spmv_n4000.npz")
     x = np.random.default_rng(11).standard_normal(N)
     row_scale = np.abs(Hh) @ np.abs(x)
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         H.set_variant(variant)
         _within(hip.HipVector(x).applyOp(H).array, g["y"], 1e-14 * row_scale)
         y = hip.HipContext.default().alloc(N)
@@ -146,7 +146,7 @@ def test_spmv_ragged_empty_long_and_unsorted_rows(hip):
     ref = A @ x
     scale = sp.csr_matrix((np.abs(val), col.copy(), rowptr.copy()), shape=(n, n)) @ np.abs(x) + 1e-300
     H = hip.HipCsrOperator.from_csr_arrays(rowptr, col, val, n)
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         H.set_variant(variant)
         got = hip.HipVector(x).applyOp(H).array
         _within(got, ref, 2e-14 * scale)
@@ -306,7 +306,7 @@ def test_full_size_operator_properties(hip):
     rhs = hip.HipVector.linearCombination([HX, HY], [2.0, -3.0])
     d = hip.HipVector.linearCombination([lhs, rhs], [1.0, -1.0])
     assert d.norm() <= 1e-14 * rhs.norm() * 10
-    for variant in (1, 2, 3):                     # CSR-vector, CSR-stream, column-window blocked
+    for variant in (1, 2, 3, 4):                     # CSR-vector, CSR-stream, column-window blocked
         H.set_variant(variant)
         hv = X.applyOp(H)
         d = hip.HipVector.linearCombination([hv, HX], [1.0, -1.0])
