@@ -80,6 +80,10 @@ extern "C" int hipeig_comm_init(hipeig_ctx* c, int nranks, int rank, const void*
   c->comm = comm;
   c->nranks = nranks;
   c->rank = rank;
+  // HIPEIG_FORCE_COLLECTIVES=1 keeps the all-gather / all-reduce path active on a one-rank
+  // communicator, so the RCCL plumbing can be exercised on a single-GPU box.
+  const char* force = getenv("HIPEIG_FORCE_COLLECTIVES");
+  c->collectives = (nranks > 1) || (force && atoi(force) != 0);
   c->row_counts = (int64_t*)calloc((size_t)nranks, sizeof(int64_t));
   return 0;
 }
@@ -90,6 +94,7 @@ extern "C" int hipeig_comm_destroy(hipeig_ctx* c) {
     g_rccl.CommDestroy((ncclComm_t)c->comm);
     c->comm = nullptr;
   }
+  c->collectives = 0;
   c->nranks = 1;
   c->rank = 0;
   return 0;
@@ -103,7 +108,7 @@ extern "C" int hipeig_comm_info(hipeig_ctx* c, int* nranks, int* rank) {
 
 // SUM all-reduce of `count` doubles in place on the compute stream.
 int hipeig_allreduce_sum(hipeig_ctx* c, double* d_buf, int count) {
-  if (!c->comm || c->nranks == 1) return 0;
+  if (!c->collectives) return 0;
   RCCL_CHECK(g_rccl.AllReduce(d_buf, d_buf, (size_t)count, NCCL_FLOAT64, NCCL_SUM,
                               (ncclComm_t)c->comm, c->stream));
   return 0;
@@ -112,7 +117,7 @@ int hipeig_allreduce_sum(hipeig_ctx* c, double* d_buf, int count) {
 // Gather the row counts of every rank (host result in ctx->row_counts) and size the
 // gathered-operand buffer: rank r's slice lives at x_full + r*stride, stride = max count.
 int hipeig_comm_setup_rows(hipeig_ctx* c, int64_t nrows_local, int64_t* stride_out) {
-  if (!c->comm || c->nranks == 1) {
+  if (!c->collectives) {
     *stride_out = nrows_local;
     return 0;
   }
@@ -135,13 +140,13 @@ int hipeig_comm_setup_rows(hipeig_ctx* c, int64_t nrows_local, int64_t* stride_o
 }
 
 // All-gather of the operand: every rank contributes its slice, in place inside x_full.
-int hipeig_allgather_x(hipeig_ctx* c, const double* x_local, int64_t n_local,
+int hipeig_allgather_x(hipeig_ctx* c, const double* x_local, int64_t n_local, int64_t stride,
                        const double** x_full_out) {
-  if (!c->comm || c->nranks == 1) {
+  if (!c->collectives) {
     *x_full_out = x_local;
     return 0;
   }
-  const int64_t stride = c->x_full_n / c->nranks;
+  HIPEIG_REQUIRE(stride >= n_local && stride * c->nranks <= c->x_full_n, "operand buffer smaller than the partition");
   double* mine = c->x_full + (int64_t)c->rank * stride;
   HIPEIG_CHECK(hipMemcpyAsync(mine, x_local, (size_t)n_local * sizeof(double),
                               hipMemcpyDeviceToDevice, c->stream));

@@ -68,6 +68,7 @@ struct hipeig_ctx {
   // distributed
   void* comm;                // ncclComm_t
   int nranks, rank;
+  int collectives;           // 1 when reductions / operator applications must go through RCCL
   double* x_full;            // all-gathered operand of the operator
   int64_t x_full_n;
   int64_t* row_counts;       // rows per rank (host), length nranks
@@ -93,6 +94,7 @@ struct hipeig_csr {
   int64_t gather_len;        // length of the gathered operand (ncols, or stride*nranks)
   int variant;               // 0 = auto, 1 = CSR-vector, 2 = CSR-stream, 3 = TCOO (wave units), 4 = TCOO-W
   int last_variant;          // variant used by the most recent launch (0 = none yet)
+  int last_launches;         // kernel launches (sweeps) one product with that variant takes
   int lanes_per_row;         // sub-wave width used to reduce one row
   int64_t col_stride;        // x_full stride per rank when columns were remapped (0 = global)
   int64_t bytes;
@@ -101,7 +103,7 @@ struct hipeig_csr {
 // ---- collectives (comm.hip); no-ops without a communicator ---------------------------
 int hipeig_comm_setup_rows(hipeig_ctx* ctx, int64_t nrows_local, int64_t* stride_out);
 int hipeig_allreduce_sum(hipeig_ctx* ctx, double* d_buf, int count);
-int hipeig_allgather_x(hipeig_ctx* ctx, const double* x_local, int64_t n_local,
+int hipeig_allgather_x(hipeig_ctx* ctx, const double* x_local, int64_t n_local, int64_t stride,
                        const double** x_full_out);
 
 // ---- device helpers ------------------------------------------------------------------

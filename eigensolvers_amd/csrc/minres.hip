@@ -271,7 +271,7 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   double* pA = c->d_partials;
   double* pC = c->d_partials + HIPEIG_MAX_PARTIALS;
   double* pD = c->d_partials + 2 * HIPEIG_MAX_PARTIALS;
-  const bool dist = c->comm && c->nranks > 1;
+  const bool dist = c->collectives != 0;
   double* red = c->d_scalars + 2048;    // reduced sums for the distributed path
   MinresArgs a;
   a.sigma = sigma; a.sign = sign; a.rtol = rtol; a.maxiter = maxiter;
@@ -294,7 +294,7 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
       double* w1 = W[(k + 1) % 3];
       double* w2 = W[(k + 2) % 3];
       const double* xg = nullptr;
-      if (hipeig_allgather_x(c, r2, n, &xg)) return 4;
+      if (hipeig_allgather_x(c, r2, n, A->col_stride, &xg)) return 4;
       if (variant == 4) {
         TcooView tv = tview;
         for (int sw = 0; sw < nsweepA; ++sw) {

@@ -109,7 +109,7 @@ static int launch_spmv(hipeig_ctx* c, hipeig_csr* A, double a_self, double a_sum
                        const double* x, double* y) {
   if (A->nrows == 0) return 0;
   const double* xg = nullptr;
-  if (hipeig_allgather_x(c, x, A->nrows, &xg)) return 4;
+  if (hipeig_allgather_x(c, x, A->nrows, A->col_stride, &xg)) return 4;
   AxpyEpilogue epi{a_self, a_sum, x, y};
   const int variant = hipeig_csr_pick_variant(c, A);
   if (variant < 0) return 1;
@@ -383,6 +383,17 @@ int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A) {
     if (rc == 2) variant = 2;
   }
   A->last_variant = variant;
+  A->last_launches = 1;
+  if (variant == 4) {
+    int g = A->w_wgs_per_sweep < A->w_nunits ? A->w_wgs_per_sweep : A->w_nunits;
+    A->last_launches = (A->w_nunits + g - 1) / g;
+  } else if (variant == 3) {
+    int64_t g = A->t_wgs_per_sweep;
+    const int64_t need = (A->t_nunits + 3) / 4;
+    if (g > need) g = need;
+    if (g > HIPEIG_MAX_PARTIALS) g = HIPEIG_MAX_PARTIALS;
+    A->last_launches = (int)((A->t_nunits + g * 4 - 1) / (g * 4));
+  }
   return variant;
 }
 
@@ -426,7 +437,7 @@ int hipeig_csr_finalize(hipeig_ctx* c, hipeig_csr* A, const int32_t* rowptr32) {
   // distributed: gather row counts, size x_full and remap global columns to its layout
   int64_t stride = 0;
   if (hipeig_comm_setup_rows(c, A->nrows, &stride)) return 4;
-  if (c->comm && c->nranks > 1) {
+  if (c->collectives) {
     std::vector<int64_t> offs(c->nranks + 1, 0);
     for (int k = 0; k < c->nranks; ++k) offs[k + 1] = offs[k] + c->row_counts[k];
     HIPEIG_REQUIRE(offs[c->nranks] == A->ncols, "row counts over ranks must add up to ncols");
@@ -499,7 +510,7 @@ extern "C" int hipeig_csr_destroy(hipeig_ctx* c, hipeig_csr* A) {
 
 extern "C" int hipeig_csr_info(hipeig_csr* A, int64_t info[8]) {
   info[0] = A->nrows; info[1] = A->ncols; info[2] = A->nnz; info[3] = A->row_offset;
-  info[4] = A->last_variant; info[5] = A->bytes; info[6] = A->n_row_blocks; info[7] = A->lanes_per_row;
+  info[4] = A->last_variant; info[5] = A->bytes; info[6] = A->n_row_blocks; info[7] = A->last_launches;
   return 0;
 }
 

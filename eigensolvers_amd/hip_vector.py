@@ -193,6 +193,12 @@ class HipCsrOperator:
         _lib.call("hipeig_csr_info", self.handle, info)
         return self.VARIANTS[int(info[4])]
 
+    def launches_per_apply(self):
+        """Kernel launches (sweeps) one product takes with the variant last used."""
+        info = (C.c_int64 * 8)()
+        _lib.call("hipeig_csr_info", self.handle, info)
+        return max(1, int(info[7]))
+
     def to_scipy(self):
         import scipy.sparse as sp
         rp = np.empty(self.nrows + 1, dtype=np.int64)

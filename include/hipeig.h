@@ -117,7 +117,7 @@ int hipeig_csr_generate(hipeig_ctx* ctx, int64_t N, int64_t row_begin, int64_t r
 int hipeig_csr_destroy(hipeig_ctx* ctx, hipeig_csr* A);
 /* info[0]=nrows [1]=ncols [2]=nnz [3]=row_offset [4]=kernel variant of the last launch
  * (1 CSR-vector, 2 CSR-stream, 3/4 column-window blocked with wave / workgroup units)
- * [5]=device bytes [6]=row blocks                                                        */
+ * [5]=device bytes [6]=row blocks [7]=kernel launches (sweeps) per product of that variant */
 int hipeig_csr_info(hipeig_csr* A, int64_t info[8]);
 /* copy the device CSR (local rows) back to the host; pass NULL to skip an array          */
 int hipeig_csr_download(hipeig_ctx* ctx, hipeig_csr* A, int64_t* rowptr, int32_t* col,

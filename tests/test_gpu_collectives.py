@@ -1,0 +1,55 @@
+"""The RCCL code path on ONE GPU: a one-rank communicator with HIPEIG_FORCE_COLLECTIVES=1
+routes every reduction through ncclAllReduce and every operator application through the
+in-place ncclAllGather + column remap, exactly as an N-rank run does.  (Multi-rank runs need
+several GPUs; the driver's scaling bench covers those.)"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_golden
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r"""
+import json, sys, numpy as np
+sys.path.insert(0, %(repo)r)
+import eigensolvers_amd as ea
+from eigensolvers_amd.generators import gapped_csr_host, guess_vector
+ctx = ea.HipContext(0); ea.HipContext._default = ctx
+ctx.attach_comm(1, 0, ctx.new_unique_id())
+N = 4000
+H = ea.HipCsrOperator.generate(N, 32, seed=7, ctx=ctx)
+Hh = gapped_csr_host(N, 32, seed=7)
+x = np.random.default_rng(3).standard_normal(N)
+out = {}
+for variant in (1, 2, 3, 4):
+    H.set_variant(variant)
+    y = ea.HipVector(x, ctx=ctx).applyOp(H).array
+    out["spmv_err_%%d" %% variant] = float(np.max(np.abs(y - Hh @ x)))
+H.set_variant(0)
+X = ea.HipVector(x, ctx=ctx)
+out["dot_err"] = abs(X.vdot(X) - float(np.dot(x, x)))
+opts = {"linearSystemArgs": {"linearSolver": "minres", "linearIter": 2000, "linear_tol": 1e-10}}
+ev, Y, st = ea.inexactLanczosDiagonalization(H, ea.HipVector(guess_vector(N, 1).copy(), opts, ctx=ctx),
+                                             0.02, 8, 10, 1e-13, writeOut=False)
+out.update(ev0=float(ev[0]), cumIter=int(st["cumIter"]), conv=bool(st["isConverged"]))
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_forced_collectives_single_rank():
+    env = dict(os.environ, HIPEIG_FORCE_COLLECTIVES="1")
+    p = subprocess.run([sys.executable, "-c", CHILD % {"repo": REPO}], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    r = json.loads(line[7:])
+    for variant in (1, 2, 3, 4):
+        assert r["spmv_err_%d" % variant] < 1e-12
+    assert r["dot_err"] < 1e-9
+    g = load_golden("gapped_csr_n4000_minres.npz")
+    assert abs(r["ev0"] - g["ev"][0]) <= 1e-10 * abs(g["ev"][0])
+    assert r["cumIter"] == int(g["cumIter"]) and r["conv"]
