@@ -118,6 +118,16 @@ def main():
     per_gpu_bytes = H.algorithmic_bytes() / 1e9          # local rows, x counted once (full length)
     achieved = per_gpu_bytes / (dev_ms / a.steps / 1e3)
     nlaunch = H.launches_per_apply()                     # the blocked layouts sweep the rows in 1-2 launches
+    # HBM traffic per launch from the committed PMC pass (cannot be collected inside this process)
+    traffic, kname = None, {"csr-vector": "spmv_vector_kernel", "csr-stream": "spmv_stream_kernel",
+                            "column-window-blocked(wave)": "spmv_tcoo_kernel",
+                            "column-window-blocked(workgroup)": "spmv_tcoow_kernel"}[H.last_variant()]
+    try:
+        pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_current.json")))
+        if pmc["config"] == {"N": N, "nnz_row": a.nnz_row, "n_gpus": world}:
+            traffic = pmc["kernels"].get(kname, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        traffic = None
     out = {
         "metric": "fp64 CSR SpMV GB/s (fused shift y = sigma*x - H x)", "value": round(value, 2), "unit": "GB/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(wall / a.steps * 1e3, 4),
@@ -128,11 +138,10 @@ def main():
                    "N": N, "nnz": nnz_total, "nnz_per_row": round(nnz_total / N, 3), "sigma": a.sigma,
                    "kernel_variant": ("auto:" if a.variant == 0 else "forced:") + H.last_variant(),
                    "generator_seed": a.seed, "generate_s": round(t_gen, 2)},
-        "roofline": {"bound": "hbm", "kernel": {"csr-vector": "spmv_vector_kernel", "csr-stream": "spmv_stream_kernel",
-                                                  "column-window-blocked(wave)": "spmv_tcoo_kernel",
-                                                  "column-window-blocked(workgroup)": "spmv_tcoow_kernel"}[H.last_variant()],
+        "roofline": {"bound": "hbm", "kernel": kname,
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": "profiles/pmc_current.json (separate rocprofv3 --pmc passes)" if traffic else None,
                      "launches_per_step": nlaunch,
                      "algorithmic_bytes_per_launch": int(H.algorithmic_bytes() // nlaunch),
                      "avg_launch_ms": round(dev_ms / a.steps / nlaunch, 5),
