@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhipeig.so")
+LIB_PATH = os.environ.get("HIPEIG_LIB", os.path.join(_HERE, "libhipeig.so"))   # override: A/B builds
 
 
 class HipEigError(RuntimeError):

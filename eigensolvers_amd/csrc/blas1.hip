@@ -323,19 +323,91 @@ extern "C" int hipeig_multi_dot(hipeig_ctx* c, int64_t n, int m, const double* c
   return 0;
 }
 
+// ---- Gram blocks on the matrix cores -------------------------------------------------------
+// C[i][j] = sum_r A_i[r] * B_j[r] for a 16 x 16 block of columns: v_mfma_f64_16x16x4_f64 with
+// the ROW index r as the K dimension.  Each wave streams 64-row tiles of the (up to) 32
+// columns with coalesced loads (lane = row), transposes them through LDS ([row][col], padded
+// to 17) and feeds sixteen K-steps of 4 rows to the MFMA; the 16 x 16 fp64 accumulator stays
+// in registers for the whole sweep.  Traffic: (16 + 16) * 8N bytes per block pair, against
+// 16 * 17 * 8N for sixteen multi_dot sweeps.  Per-workgroup partial blocks are summed by
+// finalize_kernel in fixed order, like every other reduction.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+template <bool SAME>
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+gram_mfma_kernel(int64_t n, int ma, int mb, PtrTable A, PtrTable B, double* __restrict__ partials) {
+  __shared__ double sA[4][64 * 17];
+  __shared__ double sB[SAME ? 1 : 4][SAME ? 1 : 64 * 17];
+  __shared__ double red[4][256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  d4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const int64_t ntiles = (n + 63) / 64;
+  for (int64_t t0 = (int64_t)blockIdx.x * 4; t0 < ntiles; t0 += (int64_t)gridDim.x * 4) {   // uniform trip count
+    const int64_t r = (t0 + wid) * 64 + lane;
+    const bool valid = r < n;
+#pragma unroll
+    for (int cidx = 0; cidx < 16; ++cidx) {
+      sA[wid][lane * 17 + cidx] = (cidx < ma && valid) ? A.p[cidx][r] : 0.0;
+      if (!SAME) sB[wid][lane * 17 + cidx] = (cidx < mb && valid) ? B.p[cidx][r] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int o = (4 * s + (lane >> 4)) * 17 + (lane & 15);
+      const double a = sA[wid][o];
+      const double b = SAME ? a : sB[wid][o];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) red[wid][((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = acc[reg];
+  __syncthreads();
+  const int e = threadIdx.x;                       // 256 threads <-> 256 block elements
+  partials[(size_t)blockIdx.x * 256 + e] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+}
+
 extern "C" int hipeig_gram(hipeig_ctx* c, int64_t n, int ma, const double* const* A, int mb,
                            const double* const* B, double* out) {
   HIPEIG_REQUIRE(ma >= 1 && mb >= 1, "empty set");
-  // one multi_dot sweep per column of B: reads B_j once and the ma columns of A once.
-  double* col = (double*)malloc(sizeof(double) * ma);
-  HIPEIG_REQUIRE(col != nullptr, "out of host memory");
-  int rc = 0;
-  for (int j = 0; j < mb && !rc; ++j) {
-    rc = hipeig_multi_dot(c, n, ma, A, B[j], col);
-    for (int i = 0; i < ma; ++i) out[(size_t)i * mb + j] = col[i];
+  if (ma < 3 || mb < 3 || n < 64) {
+    // tiny blocks: one multi_dot sweep per column of B
+    double* col = (double*)malloc(sizeof(double) * ma);
+    HIPEIG_REQUIRE(col != nullptr, "out of host memory");
+    int rc = 0;
+    for (int j = 0; j < mb && !rc; ++j) {
+      rc = hipeig_multi_dot(c, n, ma, A, B[j], col);
+      for (int i = 0; i < ma; ++i) out[(size_t)i * mb + j] = col[i];
+    }
+    free(col);
+    return rc;
   }
-  free(col);
-  return rc;
+  int64_t g64 = ((n + 63) / 64 + 3) / 4;
+  if (g64 > 1024) g64 = 1024;                       // 2 workgroups per CU (LDS), 256 doubles of partials each
+  const int g = (int)g64;
+  double blk[256];
+  for (int ia = 0; ia < ma; ia += 16) {
+    for (int ib = 0; ib < mb; ib += 16) {
+      const int na = (ma - ia < 16) ? ma - ia : 16, nb = (mb - ib < 16) ? mb - ib : 16;
+      PtrTable ta, tb;
+      bool same = (na == nb);
+      for (int k = 0; k < 16; ++k) {
+        ta.p[k] = (k < na) ? A[ia + k] : nullptr;
+        tb.p[k] = (k < nb) ? B[ib + k] : nullptr;
+        if (ta.p[k] != tb.p[k]) same = false;
+      }
+      if (same)
+        hipLaunchKernelGGL((gram_mfma_kernel<true>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, na, nb, ta, tb, c->d_partials);
+      else
+        hipLaunchKernelGGL((gram_mfma_kernel<false>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, na, nb, ta, tb, c->d_partials);
+      HIPEIG_CHECK(hipGetLastError());
+      if (finalize_to_host(c, g, 256, blk)) return 4;
+      for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) out[(size_t)(ia + i) * mb + (ib + j)] = blk[i * 16 + j];
+    }
+  }
+  return 0;
 }
 
 // ---- Gram-Schmidt ------------------------------------------------------------------------

@@ -121,7 +121,12 @@ __device__ __forceinline__ void csr_vector_sweep(const CsrView& A, const double*
 // so the summation order is fixed and results are reproducible.
 #define TCOO_MAX_WBITS 18
 #define TCOO_MAX_RW 2560                 // 20 KiB of LDS per wave, 8 waves per CU
-#define TCOO_UNROLL 8
+#ifndef TCOO_UNROLL
+#define TCOO_UNROLL 4
+#endif
+#ifndef TCOOW_INTERLEAVE
+#define TCOOW_INTERLEAVE 0   // 1: the waves of a workgroup take adjacent 64-element groups (instruction-level interleave)
+#endif
 
 struct TcooView {
   const uint32_t* __restrict__ idx;
@@ -229,7 +234,9 @@ __device__ __forceinline__ void tcoo_sweep(const TcooView& T, const double* __re
 // (k ~ 2.1 at N = 1e7, 65 nnz/row).  The L2 request rate - not HBM - is what bounds the
 // gather (tools/gather_bench*.hip).  Adds to one row now come from several waves, so the
 // summation ORDER inside a row is not fixed run to run (values agree to rounding).
+#ifndef TCOOW_THREADS
 #define TCOOW_THREADS 1024
+#endif
 #define TCOOW_MAX_RW 20224               // 161,792 B of LDS (+ the unit's window offsets)
 
 __device__ __forceinline__ void lds_add_f64_wg(double* p, double v) {
@@ -254,14 +261,22 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
   // stream loads of batch k+1 are in flight while batch k gathers and scatters.
   const uint32_t uend = offL[T.nwin];
   const uint32_t step = (uint32_t)nw * 64 * TCOO_UNROLL;
+#if TCOOW_INTERLEAVE
+  // element j of a batch: the 16 waves cover adjacent 64-element groups at every j, so the
+  // whole CU works on one narrow column range at a time (L1 reuse across waves)
+  const uint32_t jstride = (uint32_t)nw * 64;
+  uint32_t base = offL[0] + (uint32_t)wid * 64;
+#else
+  const uint32_t jstride = 64;
   uint32_t base = offL[0] + (uint32_t)wid * 64 * TCOO_UNROLL;
+#endif
   int c = 0;
   double sink = 0.0;
   uint32_t idA[TCOO_UNROLL], idB[TCOO_UNROLL];
   double vA[TCOO_UNROLL], vB[TCOO_UNROLL];
 #define TCOO_LOAD(ID, V, BASE)                                                         \
   _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j) {                            \
-    const uint32_t q = (BASE) + lane + 64 * j;                                         \
+    const uint32_t q = (BASE) + lane + jstride * j;                                         \
     const bool ok = q < uend;                                                          \
     ID[j] = ok ? __builtin_nontemporal_load(T.idx + q) : 0xFFFFFFFFu;                  \
     V[j] = ok ? __builtin_nontemporal_load(T.val + q) : 0.0;                           \
@@ -270,7 +285,7 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
   {                                                                                    \
     int cw[TCOO_UNROLL];                                                               \
     _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j) {                          \
-      const uint32_t q = (BASE) + lane + 64 * j;                                       \
+      const uint32_t q = (BASE) + lane + jstride * j;                                       \
       while (c + 1 < T.nwin && q >= offL[c + 1]) ++c;                                  \
       cw[j] = c;                                                                       \
     }                                                                                  \

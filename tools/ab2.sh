@@ -1,0 +1,8 @@
+#!/bin/bash
+N=${1:-10000000}; R=${2:-64}; shift 2
+for round in 1 2; do
+ for lib in "$@"; do
+  out=$(HIPEIG_LIB=$PWD/eigensolvers_amd/$lib timeout -k 10 120 python bench.py --n $N --nnz-row $R --steps 10 --warmup 2 --no-cpu --no-lanczos 2>&1 | tail -1)
+  echo "$lib :: $(echo "$out" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], "ms/step frac", d["roofline"]["frac"])' 2>/dev/null || echo "$out" | cut -c1-300)"
+ done
+done
