@@ -168,3 +168,21 @@ def dense_test_matrix(n=100, seed=1212, ev=None):
     np.random.seed(seed)
     Q = la.qr(np.random.rand(n, n))[0]
     return Q.T @ np.diag(ev) @ Q, ev
+
+
+def sinc_dvr_harmonic(N=45, xrange=(-10.0, 10.0)):
+    """H = -d^2/dx^2 + x^2 in the Colbert-Miller sinc-DVR on N equidistant points.
+
+    Stands in for the reference's in-house ``basis.SincInfInf`` (absent from the reference tree;
+    unittests/test_stateFollowingHO.py:14-21): T_ij = (-1)^(i-j)/dx^2 * {pi^2/3 (i == j),
+    2/(i-j)^2 (i != j)} (J. Chem. Phys. 96, 1982 (1992), eq. A7), V = diag(x_i^2).  The exact
+    spectrum is 2n + 1.  Parity with the reference's own grid convention is unpinned (the
+    module is not available); the spectrum is what the test relies on."""
+    x = np.linspace(xrange[0], xrange[1], N)
+    dx = x[1] - x[0]
+    i = np.arange(N)
+    d = i[:, None] - i[None, :]
+    with np.errstate(divide="ignore"):
+        T = np.where(d == 0, np.pi ** 2 / 3.0, 2.0 / (d.astype(float) ** 2))
+    T = T * (-1.0) ** np.abs(d) / dx ** 2
+    return T + np.diag(x ** 2), x

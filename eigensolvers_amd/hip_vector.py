@@ -397,10 +397,25 @@ class HipVector(AbstractVector):
             raise TypeError("complex shifts belong to the FEAST follow-up")
         o = b.options["linearSystemArgs"]
         name = o["linearSolver"]
+        if name == "gcrotmk":
+            # numpyVector.py:161: gcrotmk(linOp, b, x0, tol, atol, maxiter) with SciPy's m = k = 20
+            from .gcrotmk import gcrotmk_device
+
+            def matvec(buf):
+                out = b.ctx.alloc(b._buf.n)
+                H.apply_shifted(sigma, buf, out, reverse=reverseGF)
+                return out
+
+            xbuf, conv, gstats = gcrotmk_device(b.ctx, matvec, b._buf, b._buf.n, rtol=float(o["linear_tol"]),
+                                                atol=float(o["linear_atol"]), maxiter=int(o["linearIter"]))
+            res = b._new(xbuf)
+            res.last_solve_stats = b.last_solve_stats = {"iterations": gstats["matvecs"], "outer": gstats["outer"]}
+            if conv != 0:
+                raise UserWarning("Warning:: Iterative solver is not converged ")
+            return res
         if name != "minres":
-            if name in ("gcrotmk", "pardiso"):
-                raise NotImplementedError(
-                    f"linearSolver={name!r} is not available on the device yet; use 'minres'")
+            if name == "pardiso":
+                raise NotImplementedError("linearSolver='pardiso' (dense LU, Fortran comparison only) is host-only")
             raise Exception("Got linear solver other than gcrotmk, minres and pardiso!")
         out = b.ctx.alloc(b._buf.n)
         info = C.c_int()

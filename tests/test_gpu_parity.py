@@ -210,7 +210,7 @@ def test_solve_matches_reference_golden_and_error_behaviour(hip, gapped4000):
     with pytest.raises(UserWarning):                              # numpyVector.py:175-177
         hip.HipVector.solve(H, hip.HipVector(b.copy(), _opts(5, 1e-12)), 0.02)
     with pytest.raises(NotImplementedError):
-        hip.HipVector.solve(H, hip.HipVector(b.copy(), {"linearSystemArgs": {"linearSolver": "gcrotmk"}}), 0.02)
+        hip.HipVector.solve(H, hip.HipVector(b.copy(), {"linearSystemArgs": {"linearSolver": "pardiso"}}), 0.02)
     with pytest.raises(Exception):
         hip.HipVector.solve(H, hip.HipVector(b.copy(), {"linearSystemArgs": {"linearSolver": "bogus"}}), 0.02)
     zero = hip.HipVector.solve(H, hip.HipVector(np.zeros(4000), _opts()), 0.02)
@@ -321,3 +321,68 @@ def test_full_size_operator_properties(hip):
     t = hip.HipVector.linearCombination([X, HX], [0.02, -1.0])
     d = hip.HipVector.linearCombination([s, t], [1.0, -1.0])
     assert d.norm() <= 1e-15 * t.norm() * 10
+
+
+def test_state_following_by_max_overlap_on_device(hip):
+    """unittests/test_stateFollowingHO.py with HipVector (MINRES as inner solver)."""
+    from eigensolvers_amd.generators import sinc_dvr_harmonic
+    Hd, _ = sinc_dvr_harmonic(45, (-10, 10))
+    w, V = la.eigh(Hd)
+    sigma = 13.1
+    idx = hip.find_nearest(w, sigma)[0]
+    opts = _opts(30000, 1e-4)
+    ref = hip.HipVector(V[:, idx + 1].copy(), opts)
+    np.random.seed(13)
+    y0 = hip.HipVector(np.random.random(45), opts)
+    ev, Y, st = hip.inexactLanczosDiagonalization(hip.HipCsrOperator.from_dense(Hd), y0, sigma, 16, 200, 1e-10,
+                                                  pick=hip.get_pick_function_maxOvlp(ref), writeOut=False)
+    assert st["isConverged"]
+    assert abs(ev[0] - w[idx + 1]) / w[idx + 1] <= 1e-4
+    np.testing.assert_allclose(abs(np.vdot(ref.array, Y[0].array)), 1, rtol=1e-2)
+
+
+# ---------------------------------------------------------------- GCROT(m,k) on the device
+def test_gcrotmk_tracks_scipy(hip, gapped4000):
+    """linearSolver="gcrotmk" (numpyVector.py:161): device GCROT(20,20) against the SciPy routine
+    the reference calls, on the shifted gapped operator and on the reference's dense test matrix."""
+    import scipy.sparse.linalg as spla
+    Hh, guess = gapped4000
+    b = guess / np.linalg.norm(guess)
+    H = hip.HipCsrOperator.from_scipy(Hh)
+    for rtol in (1e-4, 1e-10):
+        op = spla.LinearOperator(Hh.shape, matvec=lambda x: 0.02 * x - Hh @ x, dtype=np.float64)
+        xs, info = spla.gcrotmk(op, b, rtol=rtol, atol=1e-14, maxiter=2000)
+        opts = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 2000, "linear_tol": rtol,
+                                     "linear_atol": 1e-14}}
+        W = hip.HipVector.solve(H, hip.HipVector(b.copy(), opts), 0.02)
+        assert info == 0
+        # both satisfy ||b - A x|| <= rtol ||b||, so they agree to cond(A) * rtol (|sigma - lambda|_min ~ 7e-3)
+        _within(W.array, xs, max(1e-9, 300 * rtol) * np.linalg.norm(xs))
+        r = b - (0.02 * W.array - Hh @ W.array)
+        assert np.linalg.norm(r) <= rtol * np.linalg.norm(b) * 1.0001
+    with pytest.raises(UserWarning):                              # not converged -> raises like the reference
+        hip.HipVector.solve(H, hip.HipVector(b.copy(), {"linearSystemArgs": {
+            "linearSolver": "gcrotmk", "linearIter": 1, "linear_tol": 1e-12, "linear_atol": 0.0}}), 0.02)
+
+
+def test_reference_unit_tests_with_gcrotmk_on_device(hip):
+    """unittests/test_lanczos.py and test_lanczosBlock.py exactly as the reference runs them
+    (gcrotmk, tol 1e-4), with HipVector: same iteration counts, eigenvalues to the tests' bounds."""
+    opt = lambda: {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 1000, "linear_tol": 1e-4}}
+    g = load_golden("lanczos_n100_seed1212.npz")
+    A, exact = dense_test_matrix(100, 1212)
+    ev, Y, st = hip.inexactLanczosDiagonalization(hip.HipCsrOperator.from_dense(A), hip.HipVector(g["guess"].copy(), opt()),
+                                                  30, 6, 4, 1e-6, writeOut=False)
+    assert st["cumIter"] == int(g["cumIter"]) and st["isConverged"]
+    np.testing.assert_allclose(ev[:2], g["ev"], rtol=1e-6)
+    assert abs(hip.find_nearest(ev, 30)[1] - hip.find_nearest(exact, 30)[1]) <= 1e-4
+    gb = load_golden("block3_degenerate.npz")
+    Ab, _ = dense_test_matrix(100, 1212, gb["exact"])
+    v0 = [hip.HipVector(gb["guess"][:, i].copy(), opt()) for i in range(3)]
+    ev, Y, st = hip.inexactLanczosDiagonalization(hip.HipCsrOperator.from_dense(Ab), v0, gb["exact"][5] + 1.5, 6, 4, 1e-6,
+                                                  writeOut=False)
+    assert st["cumIter"] == int(gb["cumIter"])
+    np.testing.assert_allclose(ev[:3], gb["exact"][5:8], rtol=1e-6)          # test_lanczosBlock.py:54
+    w, V = np.linalg.eigh(Ab)
+    lan = np.vstack([Y[i].array for i in range(3)]).T
+    assert abs(np.abs(la.eigvals(lan.T @ V[:, 5:8])).sum() - 3) < 1e-6       # projector trace, :56-62

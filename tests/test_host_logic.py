@@ -157,3 +157,24 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_state_following_by_max_overlap():
+    """unittests/test_stateFollowingHO.py restated (the in-house `basis.SincInfInf` is replaced by
+    the Colbert-Miller sinc-DVR of generators.sinc_dvr_harmonic): follow the state above the one
+    nearest to sigma by maximum overlap."""
+    from eigensolvers_amd.generators import sinc_dvr_harmonic
+    H, _ = sinc_dvr_harmonic(45, (-10, 10))
+    w, V = la.eigh(H)
+    np.testing.assert_allclose(w[:8], 2 * np.arange(8) + 1, rtol=1e-8)         # harmonic ladder
+    sigma = 13.1
+    idx = ea.find_nearest(w, sigma)[0]
+    opts = _opts("gcrotmk", 30000, 1e-4)
+    ref = RefVector(V[:, idx + 1].copy(), opts)
+    np.random.seed(13)
+    y0 = RefVector(np.random.random(45), opts)
+    ev, Y, st = ea.inexactLanczosDiagonalization(H, y0, sigma, 16, 200, 1e-10,
+                                                 pick=ea.get_pick_function_maxOvlp(ref), writeOut=False)
+    assert st["isConverged"]
+    assert abs(ev[0] - w[idx + 1]) / w[idx + 1] <= 1e-4
+    np.testing.assert_allclose(abs(np.vdot(ref.array, Y[0].array)), 1, rtol=1e-2)
