@@ -11,12 +11,14 @@ of ``include/hipeig.h`` (``libhipeig.so``).  Importing this package does not tou
 GPU; creating a ``HipContext`` / ``HipVector`` does, and fails loudly without one.
 """
 from .abstract_vector import AbstractVector, LINDEP_DEFAULT_VALUE
-from .hip_vector import HipContext, HipCsrOperator, HipVector
+from .hip_vector import HipComplexVector, HipContext, HipCsrOperator, HipVector
+from .feast import feastDiagonalization
 from .lanczos import inexactLanczosDiagonalization, KrylovSpace, true_residual_norms
 from .subspace import (basisTransformation, find_nearest, get_pick_function_close_to_sigma,
                        get_pick_function_maxOvlp)
 
-__all__ = ["AbstractVector", "LINDEP_DEFAULT_VALUE", "HipContext", "HipCsrOperator", "HipVector",
+__all__ = ["AbstractVector", "LINDEP_DEFAULT_VALUE", "HipContext", "HipCsrOperator", "HipVector", "HipComplexVector",
+           "feastDiagonalization",
            "inexactLanczosDiagonalization", "KrylovSpace", "true_residual_norms",
            "basisTransformation", "find_nearest", "get_pick_function_close_to_sigma",
            "get_pick_function_maxOvlp"]

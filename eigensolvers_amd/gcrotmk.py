@@ -59,14 +59,71 @@ class _Ops:
         return out
 
 
+class _PairOps:
+    """Complex vectors as (re, im) pairs of real device buffers: every complex operation is a
+    few real kernels (the conjugated product is two batched real reductions).  Used for the
+    complex-shifted solves of the FEAST contour, (z*I - H) x = b with real H."""
+
+    dtype = np.complex128
+
+    def __init__(self, ctx, n):
+        self.r = _Ops(ctx, n)
+
+    def new(self):
+        return (self.r.new(), self.r.new())
+
+    def zeros(self):
+        a = self.new()
+        for part in a:
+            _lib.call("hipeig_vec_fill", self.r.h, part.ptr, self.r.n, 0.0)
+        return a
+
+    def copy(self, a):
+        return (self.r.copy(a[0]), self.r.copy(a[1]))
+
+    def dot(self, a, b):                               # conj(a) . b, like BLAS zdotc
+        d = self.r.dot
+        return complex(d(a[0], b[0]) + d(a[1], b[1]), d(a[0], b[1]) - d(a[1], b[0]))
+
+    def nrm2(self, a):
+        return float(np.sqrt(self.r.dot(a[0], a[0]) + self.r.dot(a[1], a[1])))
+
+    def axpy(self, alpha, x, y):                       # y += alpha * x
+        alpha = complex(alpha)
+        self.r.axpy(alpha.real, x[0], y[0])
+        self.r.axpy(alpha.real, x[1], y[1])
+        if alpha.imag != 0.0:
+            self.r.axpy(-alpha.imag, x[1], y[0])
+            self.r.axpy(alpha.imag, x[0], y[1])
+
+    def scal(self, alpha, x):
+        alpha = complex(alpha)
+        if alpha.imag == 0.0:
+            self.r.scal(alpha.real, x[0])
+            self.r.scal(alpha.real, x[1])
+        else:
+            t = self.scaled(alpha, x)
+            _lib.call("hipeig_vec_copy", self.r.h, x[0].ptr, t[0].ptr, self.r.n)
+            _lib.call("hipeig_vec_copy", self.r.h, x[1].ptr, t[1].ptr, self.r.n)
+
+    def scaled(self, alpha, x):
+        alpha = complex(alpha)
+        out = (self.r.scaled(alpha.real, x[0]), self.r.scaled(alpha.real, x[1]))
+        if alpha.imag != 0.0:
+            self.r.axpy(-alpha.imag, x[1], out[0])
+            self.r.axpy(alpha.imag, x[0], out[1])
+        return out
+
+
 def _fgmres(ops, matvec, v0, m, atol, cs):
     """Inner Arnoldi process: A [v_0..v_j] = C B + V H with H held as Q R.
 
     Returns (Q, R, B, vs, y, res); without a preconditioner the z vectors are the v's."""
+    dt = getattr(ops, "dtype", np.float64)
     vs = [v0]
-    B = np.zeros((len(cs), m))
-    Q = np.ones((1, 1))
-    R = np.zeros((1, 0))
+    B = np.zeros((len(cs), m), dtype=dt)
+    Q = np.ones((1, 1), dtype=dt)
+    R = np.zeros((1, 0), dtype=dt)
     eps = np.finfo(np.float64).eps
     breakdown = False
     j = 0
@@ -77,23 +134,23 @@ def _fgmres(ops, matvec, v0, m, atol, cs):
             alpha = ops.dot(c, w)
             B[i, j] = alpha
             ops.axpy(-alpha, c, w)
-        hcur = np.zeros(j + 2)
+        hcur = np.zeros(j + 2, dtype=dt)
         for i, v in enumerate(vs):                     # modified Gram-Schmidt against V
             alpha = ops.dot(v, w)
             hcur[i] = alpha
             ops.axpy(-alpha, v, w)
         hcur[j + 1] = ops.nrm2(w)
         with np.errstate(over="ignore", divide="ignore"):
-            alpha = 1 / hcur[-1]
+            alpha = 1 / hcur[-1].real
         if np.isfinite(alpha):
             ops.scal(alpha, w)
-        if not (hcur[-1] > eps * w_norm):
+        if not (hcur[-1].real > eps * w_norm):
             breakdown = True                           # w in the span of the previous vectors (or NaN)
         vs.append(w)
-        Q2 = np.zeros((j + 2, j + 2), order="F")
+        Q2 = np.zeros((j + 2, j + 2), dtype=dt, order="F")
         Q2[:j + 1, :j + 1] = Q
         Q2[j + 1, j + 1] = 1
-        R2 = np.zeros((j + 2, j), order="F")
+        R2 = np.zeros((j + 2, j), dtype=dt, order="F")
         R2[:j + 1, :] = R
         Q, R = qr_insert(Q2, R2, hcur, j, which="col", overwrite_qru=True, check_finite=False)
         res = abs(Q[0, -1])                            # residual of the Hessenberg LSQ problem
@@ -105,15 +162,20 @@ def _fgmres(ops, matvec, v0, m, atol, cs):
     return Q, R, B[:, :j + 1], vs, y, res
 
 
-def gcrotmk_device(ctx, matvec, b, n, rtol=1e-5, atol=0.0, maxiter=1000, m=20, k=None):
+def gcrotmk_device(ctx, matvec, b, n, rtol=1e-5, atol=0.0, maxiter=1000, m=20, k=None, complex_pairs=False):
     """Solve A x = b; ``matvec(buf) -> new buf`` applies A on the device.
 
-    Returns ``(x_buf, info, stats)`` with SciPy's ``info`` convention."""
-    ops = _Ops(ctx, n)
+    With ``complex_pairs`` the vectors are (re, im) pairs of device buffers and the arithmetic is
+    complex (SciPy's gcrotmk on a complex LinearOperator).  Returns ``(x, info, stats)`` with
+    SciPy's ``info`` convention."""
+    ops = _PairOps(ctx, n) if complex_pairs else _Ops(ctx, n)
     if k is None:
         k = m
-    x = ops.new()
-    _lib.call("hipeig_vec_fill", ctx.handle, x.ptr, n, 0.0)
+    if complex_pairs:
+        x = ops.zeros()
+    else:
+        x = ops.new()
+        _lib.call("hipeig_vec_fill", ctx.handle, x.ptr, n, 0.0)
     r = ops.copy(b)
     b_norm = ops.nrm2(b)
     if not np.isfinite(b_norm):

@@ -287,7 +287,8 @@ class HipVector(AbstractVector):
     # ---- arithmetic (out of place, numpyVector.py:57-64) ----------------------------
     def _scaled(self, alpha):
         if isinstance(alpha, complex) or np.iscomplexobj(alpha):
-            raise TypeError("HipVector is real fp64; complex scalars belong to the FEAST follow-up")
+            alpha = complex(alpha)                      # feast.py:91-92: mult * Qe with complex mult
+            return HipComplexVector(self._scaled(alpha.real), self._scaled(alpha.imag))
         out = self.ctx.alloc(self._buf.n)
         _lib.call("hipeig_scale", self.ctx.handle, self._buf.n, float(alpha), self._buf.ptr, out.ptr)
         return self._new(out)
@@ -324,9 +325,14 @@ class HipVector(AbstractVector):
         return float(out.value)
 
     def real(self):
+        # the FEAST driver calls ``typeClass.real(mult * Qe)`` unbound, with a complex operand
+        if isinstance(self, HipComplexVector):
+            return self.re.copy()
         return self.copy()
 
     def conjugate(self):
+        if isinstance(self, HipComplexVector):
+            return HipComplexVector(self.re.copy(), self.im * -1.0)
         return self.copy()
 
     def vdot(self, other, conjugate=True):
@@ -393,10 +399,10 @@ class HipVector(AbstractVector):
             raise TypeError("HipVector.solve needs a HipCsrOperator (device-resident CSR)")
         if x0 is not None:
             raise NotImplementedError("HipVector.solve starts from a zero guess (the Lanczos path passes none)")
-        if isinstance(sigma, complex) or np.iscomplexobj(sigma):
-            raise TypeError("complex shifts belong to the FEAST follow-up")
         o = b.options["linearSystemArgs"]
         name = o["linearSolver"]
+        if isinstance(sigma, complex) or np.iscomplexobj(sigma):
+            return HipVector._solve_complex(H, b, complex(sigma), o, reverseGF)
         if name == "gcrotmk":
             # numpyVector.py:161: gcrotmk(linOp, b, x0, tol, atol, maxiter) with SciPy's m = k = 20
             from .gcrotmk import gcrotmk_device
@@ -429,6 +435,37 @@ class HipVector(AbstractVector):
         b.last_solve_stats = res.last_solve_stats
         if info.value != 0:
             # numpyVector.py:175-177: the warning is escalated to an exception
+            raise UserWarning("Warning:: Iterative solver is not converged ")
+        return res
+
+    @staticmethod
+    def _solve_complex(H, b, z, o, reverseGF):
+        """(z*I - H) x = b with a complex contour point z, real H and real b (feast.py:83-90).
+        The system is complex symmetric, so the reference uses GCROT there; the complex vectors
+        are (re, im) pairs of device buffers and one complex product costs two operator sweeps."""
+        if o["linearSolver"] != "gcrotmk":
+            raise NotImplementedError("complex shifts need linearSolver='gcrotmk' on the device "
+                                      f"(got {o['linearSolver']!r}; minres is for Hermitian systems)")
+        from .gcrotmk import gcrotmk_device
+        ctx, n = b.ctx, b._buf.n
+        sgn = -1.0 if reverseGF else 1.0
+
+        def matvec(v):                                  # sgn * ((zr + i zi)(vr + i vi) - H vr - i H vi)
+            out_r, out_i = ctx.alloc(n), ctx.alloc(n)
+            H.apply_shifted(z.real, v[0], out_r, reverse=reverseGF)         # sgn*(zr vr - H vr)
+            H.apply_shifted(z.real, v[1], out_i, reverse=reverseGF)         # sgn*(zr vi - H vi)
+            _lib.call("hipeig_axpby", ctx.handle, n, -sgn * z.imag, v[1].ptr, 1.0, out_r.ptr)
+            _lib.call("hipeig_axpby", ctx.handle, n, sgn * z.imag, v[0].ptr, 1.0, out_i.ptr)
+            return (out_r, out_i)
+
+        zero = ctx.alloc(n)
+        _lib.call("hipeig_vec_fill", ctx.handle, zero.ptr, n, 0.0)
+        x, conv, gstats = gcrotmk_device(ctx, matvec, (b._buf, zero), n, rtol=float(o["linear_tol"]),
+                                         atol=float(o["linear_atol"]), maxiter=int(o["linearIter"]),
+                                         complex_pairs=True)
+        res = HipComplexVector(b._new(x[0]), b._new(x[1]))
+        res.last_solve_stats = b.last_solve_stats = {"iterations": gstats["matvecs"], "outer": gstats["outer"]}
+        if conv != 0:
             raise UserWarning("Warning:: Iterative solver is not converged ")
         return res
 
@@ -480,3 +517,56 @@ class HipVector(AbstractVector):
         M[:, m - 1] = col
         M[m - 1, :] = col
         return M
+
+
+class HipComplexVector:
+    """A complex128 vector as two real ``HipVector`` halves - what ``solve`` returns for a complex
+    shift and what a complex scalar times a ``HipVector`` gives.  It carries just what the FEAST
+    contour step needs (feast.py:90-92): scaling by a scalar, ``real``/``conjugate``, norms and a
+    host copy.  Interleaved complex kernels are the planned replacement."""
+
+    def __init__(self, re, im):
+        self.re, self.im = re, im
+        self.options = re.options
+        self.ctx = re.ctx
+        self.last_solve_stats = None
+
+    hasExactAddition = True
+    maxD = 0
+
+    @property
+    def dtype(self):
+        return np.dtype(np.complex128)
+
+    def __len__(self):
+        return len(self.re)
+
+    @property
+    def array(self):
+        return self.re.array + 1j * self.im.array
+
+    def _scaled(self, alpha):
+        a = complex(alpha)
+        re = HipVector.linearCombination([self.re, self.im], [a.real, -a.imag])
+        im = HipVector.linearCombination([self.re, self.im], [a.imag, a.real])
+        return HipComplexVector(re, im)
+
+    def __mul__(self, other):
+        return self._scaled(other)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        return self._scaled(1.0 / complex(other))
+
+    def real(self):
+        return self.re.copy()
+
+    def conjugate(self):
+        return HipComplexVector(self.re.copy(), self.im * -1.0)
+
+    def norm(self):
+        return float(np.hypot(self.re.norm(), self.im.norm()))
+
+    def copy(self):
+        return HipComplexVector(self.re.copy(), self.im.copy())

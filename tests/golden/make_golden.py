@@ -153,6 +153,33 @@ def main():
     evs, uvs = uf.diagonalizeHamiltonian(uS, NumpyVector.matrixRepresentation(H, vecs))
     np.savez(os.path.join(HERE, "subspace_helpers.npz"), uS=uS, evs=evs,
              resid=uf.eigenvalueResidual(np.array([1.0, 2.0, 3.5]), np.array([1.1, 1.9, 3.0])))
+    # 9. FEAST (feast.py:126-244) on the reference's own test problem, unittests/test_feast.py:15-43
+    import feast as ref_feast
+    n, m0 = 100, 6
+    evf = np.linspace(1, 200, n)
+    np.random.seed(10)
+    Qf = la.qr(np.random.rand(n, n))[0]
+    Af = Qf.T @ np.diag(evf) @ Qf
+    Y0 = np.random.random((n, m0))
+    for i in range(m0):
+        Y0[:, i] = np.ones(n) * (i + 1)
+    Y1 = la.qr(Y0, mode="economic")[0]
+    opt = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 1000, "linear_tol": 1e-2}}
+    Yv = [NumpyVector(Y1[:, i].copy(), opt) for i in range(m0)]
+    import warnings as _w2
+    with _w2.catch_warnings():
+        _w2.simplefilter("ignore")
+        evF, YF, stF = ref_feast.feastDiagonalization(Af, Yv, 8, "legendre", 160.0, 166.0, 1e-10, 20, writeOut=False)
+    np.savez(os.path.join(HERE, "feast_n100.npz"), A=Af, guess=Y1, ev=evF, outerIter=stF["outerIter"],
+             residual=stF["residual"], nvec=len(YF))
+    # one quadrature term and the node/weight helper
+    gk, wk = uf.quadraturePointsWeights(8, "legendre", positiveHalf=True)
+    theta = -(np.pi * 0.5) * (gk[0] - 1)
+    z = 163.0 + 3.0 * (np.cos(theta) + 1.0j * np.sin(theta))
+    term = ref_feast.calculateQuadrature(Af, NumpyVector(Y1[:, 0].copy(), {"linearSystemArgs": {
+        "linearSolver": "gcrotmk", "linearIter": 1000, "linear_tol": 1e-10, "linear_atol": 1e-12}}), z, 3.0, theta, wk[0], 1.0)
+    gt, wt = uf.quadraturePointsWeights(6, "trapezoidal", positiveHalf=False)
+    np.savez(os.path.join(HERE, "feast_pieces.npz"), gk=gk, wk=wk, term=term.array, z=z, theta=theta, gt=gt, wt=wt)
     print("golden vectors written to", HERE)
 
 
