@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 CSR-vector, 2 CSR-stream, 3/4 column-window blocked (wave / workgroup units)")
     ap.add_argument("--no-lanczos", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--lanczos-L", type=int, default=3)
+    ap.add_argument("--lanczos-L", type=int, default=8)
+    ap.add_argument("--lanczos-maxit", type=int, default=4)
+    ap.add_argument("--lanczos-econv", type=float, default=1e-10)
     return ap.parse_args()
 
 
@@ -157,15 +159,19 @@ def main():
         tl = time.perf_counter()
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):          # keep stdout to the single JSON line
-            ev, Y, st = ea.inexactLanczosDiagonalization(H, v0, a.sigma, a.lanczos_L, 1, 1e-12, writeOut=False)
+            ev, Y, st = ea.inexactLanczosDiagonalization(H, v0, a.sigma, a.lanczos_L, a.lanczos_maxit, a.lanczos_econv,
+                                                         writeOut=False)
         barrier()
         tl = allmax(time.perf_counter() - tl)
         res = ea.true_residual_norms(H, ev, Y, 1)
-        inner = v0.last_solve_stats["iterations"] if v0.last_solve_stats else None
+        inner = Y[0].last_solve_stats["iterations"] if getattr(Y[0], "last_solve_stats", None) else None
+        if inner is None and v0.last_solve_stats:
+            inner = v0.last_solve_stats["iterations"]
         out["lanczos"] = {"cum_iters": st["cumIter"], "seconds": round(tl, 3),
                           "iters_per_s": round(st["cumIter"] / tl, 4), "ritz_value": float(ev[0]),
-                          "true_residual_norm": float(res[0]), "minres_iters_first_solve": inner,
-                          "L": a.lanczos_L, "linear_tol": 1e-10}
+                          "converged": bool(st["isConverged"]), "eigenvalue_change_residual": float(st["residual"]),
+                          "true_residual_norm": float(res[0]), "minres_iters_last_solve": inner,
+                          "L": a.lanczos_L, "maxit": a.lanczos_maxit, "eConv": a.lanczos_econv, "linear_tol": 1e-10}
 
     # ---- CPU baseline: scipy csr_matvec on a bounded row slab (rank 0, single GPU only) ----
     if rank == 0 and world == 1 and not a.no_cpu:
