@@ -314,7 +314,11 @@ int hipeig_csr_build_tcoow(hipeig_ctx* c, hipeig_csr* A) {
   HIPEIG_REQUIRE(binbits >= 4, "HIPEIG_TCOOW_BINBITS out of range");
   const int bpw = 1 << (wbits - binbits);
   const int64_t nbins = (int64_t)nwin * bpw;
-  int64_t rw = (A->nrows + c->num_cu - 1) / c->num_cu;                       // one unit per CU if it fits
+  // one unit per CU if it fits; otherwise the fewest sweeps that fit the LDS, with the rows spread
+  // evenly over sweeps * CUs units so that the last sweep is as full as the first
+  int64_t sweeps = (A->nrows + (int64_t)c->num_cu * TCOOW_MAX_RW - 1) / ((int64_t)c->num_cu * TCOOW_MAX_RW);
+  if (sweeps < 1) sweeps = 1;
+  int64_t rw = (A->nrows + sweeps * c->num_cu - 1) / (sweeps * c->num_cu);
   rw = (rw + 63) / 64 * 64;
   if (rw < 64) rw = 64;
   if (rw > TCOOW_MAX_RW) rw = TCOOW_MAX_RW;
@@ -346,8 +350,18 @@ int hipeig_csr_build_tcoow(hipeig_ctx* c, hipeig_csr* A) {
   HIPEIG_REQUIRE(run == (uint64_t)A->nnz, "TCOO-W count pass lost non-zeros");
   HIPEIG_CHECK(hipMemcpyAsync(d_cur, cnt.data(), ncnt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   HIPEIG_CHECK(hipMalloc((void**)&A->w_off, (ntile + 1) * sizeof(uint32_t)));
-  HIPEIG_CHECK(hipMalloc((void**)&A->w_idx, (size_t)A->nnz * sizeof(uint32_t)));
-  HIPEIG_CHECK(hipMalloc((void**)&A->w_val, (size_t)A->nnz * sizeof(double)));
+  {
+    // experiment knob: place the once-read stream in uncached (MTYPE_UC) memory so that it does not
+    // occupy L2 lines / tag bandwidth next to the x window
+    const char* uc = getenv("HIPEIG_TCOOW_UNCACHED");
+    if (uc && atoi(uc) != 0) {
+      HIPEIG_CHECK(hipExtMallocWithFlags((void**)&A->w_idx, (size_t)A->nnz * sizeof(uint32_t), hipDeviceMallocUncached));
+      HIPEIG_CHECK(hipExtMallocWithFlags((void**)&A->w_val, (size_t)A->nnz * sizeof(double), hipDeviceMallocUncached));
+    } else {
+      HIPEIG_CHECK(hipMalloc((void**)&A->w_idx, (size_t)A->nnz * sizeof(uint32_t)));
+      HIPEIG_CHECK(hipMalloc((void**)&A->w_val, (size_t)A->nnz * sizeof(double)));
+    }
+  }
   HIPEIG_CHECK(hipMemcpyAsync(A->w_off, off.data(), (ntile + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(tcoow_bin_kernel, dim3(grid), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_val, A->nrows,
                      (int)rw, binbits, (int)nbins, wbits, d_cur, A->w_idx, A->w_val, 1);
