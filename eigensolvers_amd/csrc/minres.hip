@@ -224,6 +224,7 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   HIPEIG_REQUIRE(maxiter >= 1, "maxiter must be positive");
   HIPEIG_REQUIRE(b != x, "x must not alias b");
   const int64_t n = A->nrows;
+  HIPEIG_REQUIRE(c->collectives || A->nrows == A->ncols, "the inner solve needs a square operator (or a row partition)");
   *info = 0;
   if (out_stats) memset(out_stats, 0, 8 * sizeof(double));
   if (hipeig_vec_fill(c, x, n, 0.0)) return 1;
@@ -262,10 +263,10 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   const TcooView tview = (variant == 4) ? hipeig_tcoow_view(A) : hipeig_tcoo_view(A);
   if (variant == 4)
     HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)hipeig_tcoow_lds_bytes(A)));
+                                     (int)HIPEIG_TCOOW_LDS_MAX));
   if (variant == 3)
     HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)hipeig_tcoo_lds_bytes(A)));
+                                     (int)HIPEIG_TCOO_LDS_MAX));
   const int gA = hipeig_spmv_grid(A, variant);
   const int gE = grid_for(n, 4);
   double* pA = c->d_partials;

@@ -110,7 +110,9 @@ static int launch_spmv(hipeig_ctx* c, hipeig_csr* A, double a_self, double a_sum
   if (A->nrows == 0) return 0;
   const double* xg = nullptr;
   if (hipeig_allgather_x(c, x, A->nrows, A->col_stride, &xg)) return 4;
-  AxpyEpilogue epi{a_self, a_sum, x, y};
+  // shift term: x restricted to this operator's rows.  Partitioned run: x IS that slice; a row
+  // slab applied to a full-length operand (single process): the slice starts at row_offset.
+  AxpyEpilogue epi{a_self, a_sum, c->collectives ? x : x + A->row_offset, y};
   const int variant = hipeig_csr_pick_variant(c, A);
   if (variant < 0) return 1;
   const CsrView v = hipeig_csr_view(A);
@@ -152,7 +154,6 @@ extern "C" int hipeig_spmv_shift(hipeig_ctx* c, hipeig_csr* A, double sigma, dou
 // thread).  count pass: non-zeros per (unit, window).  fill pass: a non-zero of row r and
 // window c goes to  off[unit][c] + (#nnz of window c in earlier rows of the unit) + (#earlier
 // nnz of window c in row r): row-major order inside every tile, independent of scheduling.
-#define TCOO_MAX_WIN 128
 
 __global__ void __launch_bounds__(256)
 tcoo_build_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
@@ -229,7 +230,8 @@ int hipeig_csr_build_tcoo(hipeig_ctx* c, hipeig_csr* A) {
   const size_t ntile = (size_t)nunits * nwin;
   HIPEIG_CHECK(hipMalloc((void**)&d_counts, ntile * sizeof(uint32_t)));
   const size_t lds = ((size_t)256 * nwin + nwin) * sizeof(uint32_t);
-  HIPEIG_CHECK(hipFuncSetAttribute((const void*)tcoo_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIPEIG_CHECK(hipFuncSetAttribute((const void*)tcoo_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(((size_t)256 * TCOO_MAX_WIN + TCOO_MAX_WIN) * sizeof(uint32_t))));
   hipLaunchKernelGGL(tcoo_build_kernel, dim3(nunits), dim3(256), lds, c->stream, A->d_rowptr, A->d_col, A->d_val,
                      A->nrows, (int)rw, nwin, wbits, d_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                      (double*)nullptr, 0);
@@ -262,7 +264,7 @@ int hipeig_csr_build_tcoo(hipeig_ctx* c, hipeig_csr* A) {
     if (const char* e = getenv("HIPEIG_TCOO_PREFETCH")) A->t_prefetch = atoi(e) != 0;   // tuning knob
   }
   HIPEIG_CHECK(hipFuncSetAttribute((const void*)spmv_tcoo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)hipeig_tcoo_lds_bytes(A)));
+                                   (int)HIPEIG_TCOO_LDS_MAX));   // the largest any operator may ask for
   A->bytes += (int64_t)A->nnz * 12 + (int64_t)(ntile + 1) * 4;
   return 0;
 }
@@ -307,7 +309,7 @@ int hipeig_csr_build_tcoow(hipeig_ctx* c, hipeig_csr* A) {
   HIPEIG_REQUIRE(wbits >= 10 && wbits <= 17, "HIPEIG_TCOOW_WBITS out of range");
   while (wbits > 10 && ((int64_t)1 << (wbits - 1)) >= A->gather_len) --wbits;
   const int nwin = (int)((A->gather_len + ((int64_t)1 << wbits) - 1) >> wbits);
-  if (nwin > 256) return 2;
+  if (nwin > TCOOW_MAX_WIN) return 2;
   int binbits = 5;                                     // 32 columns = 2 lines of x per bin (measured: 4..6 equal)                                    // 2 Ki columns = 128 lines of x per bin
   if (const char* e = getenv("HIPEIG_TCOOW_BINBITS")) binbits = atoi(e);     // tuning knob
   if (binbits > wbits) binbits = wbits;
@@ -374,7 +376,7 @@ int hipeig_csr_build_tcoow(hipeig_ctx* c, hipeig_csr* A) {
   if (per_cu < 1) per_cu = 1;
   A->w_wgs_per_sweep = per_cu * c->num_cu;
   HIPEIG_CHECK(hipFuncSetAttribute((const void*)spmv_tcoow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)hipeig_tcoow_lds_bytes(A)));
+                                   (int)HIPEIG_TCOOW_LDS_MAX));
   A->bytes += (int64_t)A->nnz * 12 + (int64_t)(ntile + 1) * 4;
   return 0;
 }

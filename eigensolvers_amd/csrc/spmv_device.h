@@ -121,6 +121,8 @@ __device__ __forceinline__ void csr_vector_sweep(const CsrView& A, const double*
 // so the summation order is fixed and results are reproducible.
 #define TCOO_MAX_WBITS 18
 #define TCOO_MAX_RW 2560                 // 20 KiB of LDS per wave, 8 waves per CU
+#define TCOO_MAX_WIN 128
+#define HIPEIG_TCOO_LDS_MAX ((size_t)4 * TCOO_MAX_RW * sizeof(double))
 #ifndef TCOO_UNROLL
 #define TCOO_UNROLL 4
 #endif
@@ -135,7 +137,8 @@ struct TcooView {
   int32_t nunits, nwin, wbits, rw;
   int32_t unit_begin;                    // first unit of this launch (one unit per wave)
   int32_t prefetch;                      // dense L2 prefetch of the next x window (0/1)
-  int32_t ablate;                        // timing experiments only: 1 = skip gathers, 2 = skip LDS adds
+  int32_t ablate;                        // timing experiments only: 1 = skip gathers, 2 = skip LDS adds,
+                                         // 4 = skip the value stream, 8 = gather from window 0 only
   int64_t nrows, gather_len;
 };
 
@@ -238,6 +241,8 @@ __device__ __forceinline__ void tcoo_sweep(const TcooView& T, const double* __re
 #define TCOOW_THREADS 1024
 #endif
 #define TCOOW_MAX_RW 20224               // 161,792 B of LDS (+ the unit's window offsets)
+#define TCOOW_MAX_WIN 256
+#define HIPEIG_TCOOW_LDS_MAX ((size_t)TCOOW_MAX_RW * sizeof(double) + (TCOOW_MAX_WIN + 2) * sizeof(uint32_t))
 
 __device__ __forceinline__ void lds_add_f64_wg(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -279,7 +284,7 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
     const uint32_t q = (BASE) + lane + jstride * j;                                         \
     const bool ok = q < uend;                                                          \
     ID[j] = ok ? __builtin_nontemporal_load(T.idx + q) : 0xFFFFFFFFu;                  \
-    V[j] = ok ? __builtin_nontemporal_load(T.val + q) : 0.0;                           \
+    V[j] = (ok && !(T.ablate & 4)) ? __builtin_nontemporal_load(T.val + q) : 1.0;     \
   }
 #define TCOO_CONSUME(ID, V, BASE)                                                      \
   {                                                                                    \
@@ -291,7 +296,7 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
     }                                                                                  \
     if (!(T.ablate & 1)) {                                                             \
       _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j)                          \
-        if (ID[j] != 0xFFFFFFFFu) V[j] *= x[((size_t)cw[j] << T.wbits) + (ID[j] & cmask)]; \
+        if (ID[j] != 0xFFFFFFFFu) V[j] *= x[((size_t)((T.ablate & 8) ? 0 : cw[j]) << T.wbits) + (ID[j] & cmask)]; \
     }                                                                                  \
     if (!(T.ablate & 2)) {                                                             \
       _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j)                          \

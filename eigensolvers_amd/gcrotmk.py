@@ -81,9 +81,16 @@ class _PairOps:
     def copy(self, a):
         return (self.r.copy(a[0]), self.r.copy(a[1]))
 
+    def _dots2(self, a, x):                            # [a_re . x, a_im . x] in one batched sweep
+        out = np.empty(2)
+        tab = (C.c_void_p * 2)(a[0].ptr, a[1].ptr)
+        _lib.call("hipeig_multi_dot", self.r.h, self.r.n, 2, C.cast(tab, C.POINTER(C.c_void_p)), x.ptr,
+                  out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
     def dot(self, a, b):                               # conj(a) . b, like BLAS zdotc
-        d = self.r.dot
-        return complex(d(a[0], b[0]) + d(a[1], b[1]), d(a[0], b[1]) - d(a[1], b[0]))
+        p, q = self._dots2(a, b[0]), self._dots2(a, b[1])      # p = [ar.br, ai.br], q = [ar.bi, ai.bi]
+        return complex(p[0] + q[1], q[0] - p[1])
 
     def nrm2(self, a):
         return float(np.sqrt(self.r.dot(a[0], a[0]) + self.r.dot(a[1], a[1])))

@@ -154,6 +154,15 @@ def test_spmv_ragged_empty_long_and_unsorted_rows(hip):
     # rectangular slab (rows 100..900 of the same matrix): what one rank of a partition holds
     slab = hip.HipCsrOperator.from_scipy(A, 100, 900)
     assert slab.shape == (800, n) and slab.row_offset == 100
+    ys = hip.HipContext.default().alloc(800)
+    for variant in (1, 2, 3, 4):                  # a slab applied to a full-length operand
+        slab.set_variant(variant)
+        slab.apply(hip.HipVector(x)._buf, ys)
+        _within(hip.HipVector(ys).array, ref[100:900], 2e-14 * scale[100:900])
+        slab.apply_shifted(0.5, hip.HipVector(x)._buf, ys)
+        _within(hip.HipVector(ys).array, 0.5 * x[100:900] - ref[100:900], 2e-14 * (scale[100:900] + abs(x[100:900])))
+    with pytest.raises(Exception):
+        hip.HipVector.solve(slab, hip.HipVector(x[:800].copy(), _opts()), 0.02)   # not square
     # degenerate shapes
     E = hip.HipCsrOperator.from_csr_arrays(np.zeros(5, dtype=np.int64), np.zeros(0, np.int32), np.zeros(0), 4)
     np.testing.assert_array_equal(hip.HipVector(np.ones(4)).applyOp(E).array, np.zeros(4))
@@ -315,6 +324,18 @@ def test_full_size_operator_properties(hip):
     # rows 400000..400500 against the host generator's slab
     slab = gapped_csr_host(N, 32, seed=7, row_begin=400000, row_end=400500)
     _within(HX.array[400000:400500], slab @ x, 1e-13 * (np.abs(slab) @ np.abs(x)))
+    # two operators with different LDS footprints used alternately (kernel attributes are global)
+    small_h = gapped_csr_host(4000, 32, seed=7)
+    small = hip.HipCsrOperator.from_scipy(small_h)
+    xs = rng.standard_normal(4000)
+    for variant in (4, 3):
+        small.set_variant(variant); H.set_variant(variant)
+        for _ in range(2):
+            ys = hip.HipVector(xs).applyOp(small).array
+            _within(ys, small_h @ xs, 1e-13 * (np.abs(small_h) @ np.abs(xs)))
+            d = hip.HipVector.linearCombination([X.applyOp(H), HX], [1.0, -1.0])
+            assert d.norm() <= 1e-14 * HX.norm()
+    H.set_variant(0)
     buf = hip.HipContext.default().alloc(N)
     H.apply_shifted(0.02, X._buf, buf)
     s = hip.HipVector(buf)

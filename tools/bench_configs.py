@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Run the other BASELINE.json configurations once on one MI355X and write a JSON report.
+
+bench.py measures the headline configuration (N = 1e7, 65 nnz/row).  This script covers the rest
+as parity / behaviour cases with timings:
+
+  #1  dense random Hermitian N = 2000 (examples/driver_numpyVector.py shape), gcrotmk: HipVector on the
+      GPU next to the CPU oracle on the same inputs (Ritz values compared).
+  #2  random-sparse CSR N = 1e6, 33 nnz/row, single-vector Lanczos to convergence (MINRES 1e-10).
+  #3  the same operator, block Lanczos with 8 orthonormal guesses (one restart cycle).
+  #5  FEAST: window [-0.21, 0.21] around the 16 clustered eigenvalues, m0 = 20, nc = 8 (4 complex
+      contour solves per vector), GCROT - at N = 2e4 so that a run takes a minute (the complex solves
+      are host-orchestrated pair arithmetic for now).
+
+usage: python tools/bench_configs.py [out.json]
+"""
+import contextlib
+import json
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+import scipy.linalg as la
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import eigensolvers_amd as ea  # noqa: E402
+from eigensolvers_amd.generators import gapped_csr_host, guess_vector  # noqa: E402
+
+
+def timed(fn):
+    ea.HipContext.default().synchronize()
+    t = time.perf_counter()
+    out = fn()
+    ea.HipContext.default().synchronize()
+    return out, time.perf_counter() - t
+
+
+def config1():
+    from oracle import lanczos_ref
+    from oracle.numpy_vector import RefVector
+    n = 2000
+    ev = np.linspace(1, 1200, n)
+    np.random.seed(10)
+    Q = la.qr(np.random.rand(n, n))[0]
+    A = Q.T @ np.diag(ev) @ Q
+    y0 = np.random.random(n)
+    opt = lambda: {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 5000, "linear_tol": 1e-4}}
+    sigma = 640.3
+    (e_g, Y, st), t_g = timed(lambda: ea.inexactLanczosDiagonalization(
+        ea.HipCsrOperator.from_dense(A), ea.HipVector(y0.copy(), opt()), sigma, 12, 6, 1e-10, writeOut=False))
+    t0 = time.perf_counter()
+    e_c, Yc, stc = lanczos_ref.inexact_lanczos(A, RefVector(y0.copy(), opt()), sigma, 12, 6, 1e-10)
+    t_c = time.perf_counter() - t0
+    exact = ev[np.argmin(abs(ev - sigma))]
+    return {"N": n, "solver": "gcrotmk", "gpu": {"ritz": float(e_g[0]), "cumIter": st["cumIter"], "converged": bool(st["isConverged"]), "seconds": round(t_g, 3)},
+            "cpu_oracle": {"ritz": float(e_c[0]), "cumIter": stc["cumIter"], "converged": bool(stc["isConverged"]), "seconds": round(t_c, 3)},
+            "exact": float(exact), "rel_diff_gpu_cpu": abs(e_g[0] - e_c[0]) / abs(e_c[0]), "rel_err_gpu": abs(e_g[0] - exact) / exact}
+
+
+def config2_3():
+    N = 1_000_000
+    H = ea.HipCsrOperator.generate(N, 32, seed=7)
+    opt = lambda tol=1e-10: {"linearSystemArgs": {"linearSolver": "minres", "linearIter": 3000, "linear_tol": tol}}
+    v0 = ea.HipVector(guess_vector(N, 1).copy(), opt())
+    (ev, Y, st), t = timed(lambda: ea.inexactLanczosDiagonalization(H, v0, 0.02, 8, 6, 1e-12, writeOut=False))
+    res = ea.true_residual_norms(H, ev, Y, 1)[0]
+    c2 = {"N": N, "nnz": int(H.nnz), "ritz": float(ev[0]), "cumIter": st["cumIter"], "converged": bool(st["isConverged"]),
+          "eigenvalue_change": float(st["residual"]), "true_residual_norm": float(res), "seconds": round(t, 3),
+          "lanczos_iters_per_s": round(st["cumIter"] / t, 3), "minres_iters_last_solve": Y[0].last_solve_stats and Y[0].last_solve_stats["iterations"],
+          "kernel": H.last_variant()}
+    Q8 = la.qr(np.random.default_rng(5).standard_normal((N, 8)), mode="economic")[0]
+    v8 = [ea.HipVector(Q8[:, i].copy(), opt(1e-8)) for i in range(8)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        (evb, Yb, stb), tb = timed(lambda: ea.inexactLanczosDiagonalization(H, v8, 0.02, 3, 1, 1e-7, writeOut=False))
+    c3 = {"N": N, "nBlock": 8, "L": 3, "cumIter": stb["cumIter"], "basis": len(Yb), "seconds": round(tb, 3),
+          "solves": 8 * stb["cumIter"], "solves_per_s": round(8 * stb["cumIter"] / tb, 3),
+          "lowest_block_values": [float(v) for v in np.sort(evb[:8])] if not np.any(np.isnan(evb)) else None,
+          "lindep_exit": bool(np.any(np.isnan(evb)))}
+    return c2, c3
+
+
+def config5():
+    N, m0 = 20_000, 18
+    H = ea.HipCsrOperator.generate(N, 32, seed=7)
+    Y0 = la.qr(np.random.default_rng(9).standard_normal((N, m0)), mode="economic")[0]
+    opt = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 2000, "linear_tol": 1e-4, "linear_atol": 1e-12}}
+    Y = [ea.HipVector(Y0[:, i].copy(), opt) for i in range(m0)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        (ev, Yf, st), t = timed(lambda: ea.feastDiagonalization(H, Y, 8, "legendre", -0.21, 0.21, 1e-9, 4, writeOut=False))
+    inside = np.sort(ev[(ev >= -0.21) & (ev <= 0.21)])
+    res = ea.true_residual_norms(H, ev, Yf)
+    return {"N": N, "m0": m0, "contour_points": 4, "outerIter": st["outerIter"], "residual": st["residual"],
+            "eigenvalues_in_window": [float(v) for v in inside], "count_in_window": int(len(inside)),
+            "max_true_residual_in_window": float(max(r for e, r in zip(ev, res) if -0.21 <= e <= 0.21)),
+            "seconds": round(t, 3)}
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "gpurun_out", "configs.json")
+    rep = {"device": ea.HipContext.default().device_info()["name"]}
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+
+    def save():
+        json.dump(rep, open(out, "w"), indent=1)
+
+    with contextlib.redirect_stdout(sys.stderr):
+        rep["config2_single_vector"], rep["config3_block8"] = config2_3()
+        save()
+        rep["config1_dense_plumbing"] = config1()
+        save()
+        rep["config5_feast"] = config5()
+        save()
+    print(json.dumps(rep))
+
+
+if __name__ == "__main__":
+    main()
