@@ -101,7 +101,8 @@ def config5():
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "gpurun_out", "configs.json")
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    out = args[0] if args else os.path.join(REPO, "gpurun_out", "configs.json")
     rep = {"device": ea.HipContext.default().device_info()["name"]}
     os.makedirs(os.path.dirname(out), exist_ok=True)
 
@@ -113,8 +114,9 @@ def main():
         save()
         rep["config1_dense_plumbing"] = config1()
         save()
-        rep["config5_feast"] = config5()
-        save()
+        if "--feast" in sys.argv:                 # slow for now: complex solves are host-orchestrated pair arithmetic
+            rep["config5_feast"] = config5()
+            save()
     print(json.dumps(rep))
 
 
