@@ -65,7 +65,10 @@ def main():
     dist = None
     if world > 1:
         dist = D.init_process_group_gloo()
-    ctx = ea.HipContext(local_rank)
+    try:
+        ctx = ea.HipContext(local_rank)
+    except ea._lib.HipEigError:                      # launcher already narrowed the visible devices to one
+        ctx = ea.HipContext(0)
     ea.HipContext._default = ctx
     if world > 1:
         D.attach_rccl(ctx)

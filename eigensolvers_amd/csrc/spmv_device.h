@@ -130,6 +130,14 @@ __device__ __forceinline__ void csr_vector_sweep(const CsrView& A, const double*
 #define TCOOW_INTERLEAVE 0   // 1: the waves of a workgroup take adjacent 64-element groups (instruction-level interleave)
 #endif
 
+// Timing experiments (skip gathers / LDS adds / the value stream / window switching) are compiled
+// in only with -DHIPEIG_EXPERIMENTS (make EXPERIMENTS=1); the shipped kernels carry none of it.
+#ifdef HIPEIG_EXPERIMENTS
+#define TCOO_ABL(T, bit) ((T).ablate & (bit))
+#else
+#define TCOO_ABL(T, bit) 0
+#endif
+
 struct TcooView {
   const uint32_t* __restrict__ idx;
   const double* __restrict__ val;
@@ -206,12 +214,12 @@ __device__ __forceinline__ void tcoo_sweep(const TcooView& T, const double* __re
           id[j] = ok ? __builtin_nontemporal_load(T.idx + q) : 0xFFFFFFFFu;
           v[j] = ok ? __builtin_nontemporal_load(T.val + q) : 0.0;
         }
-        if (!(T.ablate & 1)) {
+        if (!(TCOO_ABL(T, 1))) {
 #pragma unroll
           for (int j = 0; j < TCOO_UNROLL; ++j)
             if (id[j] != 0xFFFFFFFFu) v[j] *= xw[id[j] & cmask];
         }
-        if (!(T.ablate & 2)) {
+        if (!(TCOO_ABL(T, 2))) {
 #pragma unroll
           for (int j = 0; j < TCOO_UNROLL; ++j)
             if (id[j] != 0xFFFFFFFFu) lds_add_f64(yacc + (id[j] >> T.wbits), v[j]);
@@ -246,6 +254,23 @@ __device__ __forceinline__ void tcoo_sweep(const TcooView& T, const double* __re
 
 __device__ __forceinline__ void lds_add_f64_wg(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// x gather of the TCOO-W sweep.  TCOOW_GATHER_MODE (build-time experiment): 0 plain load,
+// 1 non-temporal, 2 sc1 (bypasses the CU's L1), 3 sc0 sc1.
+#ifndef TCOOW_GATHER_MODE
+#define TCOOW_GATHER_MODE 0
+#endif
+__device__ __forceinline__ double tcoow_gather(const double* p) {
+#if TCOOW_GATHER_MODE == 1
+  return __builtin_nontemporal_load(p);
+#elif TCOOW_GATHER_MODE == 2
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // global_load ... sc1
+#elif TCOOW_GATHER_MODE == 3
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);    // global_load ... sc0 sc1
+#else
+  return *p;
+#endif
 }
 
 template <class Epi>
@@ -284,7 +309,7 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
     const uint32_t q = (BASE) + lane + jstride * j;                                         \
     const bool ok = q < uend;                                                          \
     ID[j] = ok ? __builtin_nontemporal_load(T.idx + q) : 0xFFFFFFFFu;                  \
-    V[j] = (ok && !(T.ablate & 4)) ? __builtin_nontemporal_load(T.val + q) : 1.0;     \
+    V[j] = (ok && !(TCOO_ABL(T, 4))) ? __builtin_nontemporal_load(T.val + q) : 1.0;     \
   }
 #define TCOO_CONSUME(ID, V, BASE)                                                      \
   {                                                                                    \
@@ -294,11 +319,11 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
       while (c + 1 < T.nwin && q >= offL[c + 1]) ++c;                                  \
       cw[j] = c;                                                                       \
     }                                                                                  \
-    if (!(T.ablate & 1)) {                                                             \
+    if (!(TCOO_ABL(T, 1))) {                                                             \
       _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j)                          \
-        if (ID[j] != 0xFFFFFFFFu) V[j] *= x[((size_t)((T.ablate & 8) ? 0 : cw[j]) << T.wbits) + (ID[j] & cmask)]; \
+        if (ID[j] != 0xFFFFFFFFu) V[j] *= tcoow_gather(x + (((size_t)((TCOO_ABL(T, 8)) ? 0 : cw[j]) << T.wbits) + (ID[j] & cmask))); \
     }                                                                                  \
-    if (!(T.ablate & 2)) {                                                             \
+    if (!(TCOO_ABL(T, 2))) {                                                             \
       _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j)                          \
         if (ID[j] != 0xFFFFFFFFu) lds_add_f64_wg(yacc + (ID[j] >> T.wbits), V[j]);     \
     } else {                                                                           \
