@@ -443,6 +443,124 @@ mgs_update_kernel(int64_t n, const double* __restrict__ t, const double* __restr
   }
 }
 
+// ---- sequential MGS projection with the coefficients kept on the device -------------------
+// w <- w - sum_j c_j V_j with c_j = <V_j, w_current> taken one column after the other (the
+// Arnoldi orthogonalisation of GMRES-type solvers: scipy _fgmres, the loop the reference's
+// gcrotmk runs).  Two launches per column and no host round trip: the update kernel sums the
+// dot kernel's partials in its prologue (identical value in every workgroup), workgroup 0 stores
+// the coefficient, and all m coefficients are copied back once at the end.
+// `npart` = 1 means p[0..nval) already holds reduced (all-reduced) values.
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+mgsp_dot_kernel(int64_t n, const double* __restrict__ v, const double* __restrict__ w, double* __restrict__ partials) {
+  __shared__ double lds[4];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double a = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a = fma(v[i], w[i], a);
+  a = block_reduce_sum(a, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = a;
+}
+
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+mgsp_update_kernel(int64_t n, const double* __restrict__ p, int npart, const double* __restrict__ v,
+                   double* __restrict__ w, double* __restrict__ coef_out) {
+  __shared__ double lds[4];
+  const double cj = (npart == 1) ? p[0] : block_sum_partials(p, npart, lds);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *coef_out = cj;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) w[i] = fma(-cj, v[i], w[i]);
+}
+
+// complex vectors as (re, im) pairs: c = conj(v).w = (vr.wr + vi.wi) + i (vr.wi - vi.wr)
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+mgsp_pair_dot_kernel(int64_t n, const double* __restrict__ vr, const double* __restrict__ vi,
+                     const double* __restrict__ wr, const double* __restrict__ wi, double* __restrict__ partials) {
+  __shared__ double lds[4];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double re = 0.0, im = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double a = vr[i], b = vi[i], x = wr[i], y = wi[i];
+    re = fma(a, x, re); re = fma(b, y, re);
+    im = fma(a, y, im); im = fma(-b, x, im);
+  }
+  re = block_reduce_sum(re, lds);
+  im = block_reduce_sum(im, lds);
+  if (threadIdx.x == 0) { partials[blockIdx.x] = re; partials[gridDim.x + blockIdx.x] = im; }
+}
+
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+mgsp_pair_update_kernel(int64_t n, const double* __restrict__ p, int npart, int pstride,
+                        const double* __restrict__ vr, const double* __restrict__ vi,
+                        double* __restrict__ wr, double* __restrict__ wi, double* __restrict__ coef_out) {
+  __shared__ double lds[4];
+  const double cr = (npart == 1) ? p[0] : block_sum_partials(p, npart, lds);
+  const double ci = (npart == 1) ? p[1] : block_sum_partials(p + pstride, npart, lds);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { coef_out[0] = cr; coef_out[1] = ci; }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double a = vr[i], b = vi[i];
+    wr[i] = wr[i] - (cr * a - ci * b);           // w -= c * v
+    wi[i] = wi[i] - (cr * b + ci * a);
+  }
+}
+
+__global__ void mgsp_reduce_kernel(const double* __restrict__ p, int npart, int nval, int pstride, double* __restrict__ out) {
+  __shared__ double lds[4];
+  for (int k = 0; k < nval; ++k) {
+    const double v = block_sum_partials(p + (size_t)k * pstride, npart, lds);
+    if (threadIdx.x == 0) out[k] = v;
+  }
+}
+
+extern "C" int hipeig_mgs_project(hipeig_ctx* c, int64_t n, int m, const double* const* V, double* w, double* coeffs) {
+  HIPEIG_REQUIRE(m >= 0 && m <= 1024 && coeffs, "bad arguments");
+  if (m == 0) return 0;
+  const int g = grid_for(n, 4);
+  double* dcoef = c->d_scalars + 2560;                 // m doubles
+  double* red = c->d_scalars + 3600;
+  for (int j = 0; j < m; ++j) {
+    hipLaunchKernelGGL(mgsp_dot_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, V[j], w, c->d_partials);
+    const double* p = c->d_partials;
+    int npart = g;
+    if (c->collectives) {
+      hipLaunchKernelGGL(mgsp_reduce_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, c->d_partials, g, 1, g, red);
+      if (hipeig_allreduce_sum(c, red, 1)) return 4;
+      p = red; npart = 1;
+    }
+    hipLaunchKernelGGL(mgsp_update_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, p, npart, V[j], w, dcoef + j);
+  }
+  HIPEIG_CHECK(hipGetLastError());
+  HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dcoef, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  memcpy(coeffs, c->h_scalars, sizeof(double) * m);
+  return 0;
+}
+
+extern "C" int hipeig_pair_mgs_project(hipeig_ctx* c, int64_t n, int m, const double* const* Vre,
+                                       const double* const* Vim, double* wre, double* wim, double* coeffs) {
+  HIPEIG_REQUIRE(m >= 0 && m <= 512 && coeffs, "bad arguments");
+  if (m == 0) return 0;
+  const int g = grid_for(n, 4);
+  double* dcoef = c->d_scalars + 2560;                 // 2m doubles
+  double* red = c->d_scalars + 3600;
+  for (int j = 0; j < m; ++j) {
+    hipLaunchKernelGGL(mgsp_pair_dot_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, Vre[j], Vim[j], wre, wim, c->d_partials);
+    const double* p = c->d_partials;
+    int npart = g;
+    if (c->collectives) {
+      hipLaunchKernelGGL(mgsp_reduce_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, c->d_partials, g, 2, g, red);
+      if (hipeig_allreduce_sum(c, red, 2)) return 4;
+      p = red; npart = 1;
+    }
+    hipLaunchKernelGGL(mgsp_pair_update_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, p, npart, g,
+                       Vre[j], Vim[j], wre, wim, dcoef + 2 * j);
+  }
+  HIPEIG_CHECK(hipGetLastError());
+  HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dcoef, sizeof(double) * 2 * m, hipMemcpyDeviceToHost, c->stream));
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  memcpy(coeffs, c->h_scalars, sizeof(double) * 2 * m);
+  return 0;
+}
+
 extern "C" int hipeig_orthonormalize(hipeig_ctx* c, int64_t n, int m, const double* const* Y,
                                      double* x, double lindep, int method, double* innerprod,
                                      int* is_lindep) {

@@ -58,6 +58,24 @@ class _Ops:
         _lib.call("hipeig_scale", self.h, self.n, float(alpha), x.ptr, out.ptr)
         return out
 
+    def mgs_project(self, vs, w):
+        """Sequential MGS of w against vs on the device; returns the coefficients."""
+        out = np.empty(len(vs))
+        if len(vs):
+            tab = (C.c_void_p * len(vs))(*[v.ptr for v in vs])
+            _lib.call("hipeig_mgs_project", self.h, self.n, len(vs), C.cast(tab, C.POINTER(C.c_void_p)), w.ptr,
+                      out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def combine(self, coeffs, vecs):
+        """sum_i coeffs[i] * vecs[i] in one pass."""
+        out = self.new()
+        cf = np.ascontiguousarray(coeffs, dtype=np.float64)
+        tab = (C.c_void_p * len(vecs))(*[v.ptr for v in vecs])
+        _lib.call("hipeig_lincomb", self.h, self.n, len(vecs), cf.ctypes.data_as(C.POINTER(C.c_double)),
+                  C.cast(tab, C.POINTER(C.c_void_p)), out.ptr)
+        return out
+
 
 class _PairOps:
     """Complex vectors as (re, im) pairs of real device buffers: every complex operation is a
@@ -121,6 +139,22 @@ class _PairOps:
             self.r.axpy(alpha.imag, x[0], out[1])
         return out
 
+    def mgs_project(self, vs, w):
+        out = np.empty(2 * len(vs))
+        if len(vs):
+            tr = (C.c_void_p * len(vs))(*[v[0].ptr for v in vs])
+            ti = (C.c_void_p * len(vs))(*[v[1].ptr for v in vs])
+            _lib.call("hipeig_pair_mgs_project", self.r.h, self.r.n, len(vs), C.cast(tr, C.POINTER(C.c_void_p)),
+                      C.cast(ti, C.POINTER(C.c_void_p)), w[0].ptr, w[1].ptr, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out[0::2] + 1j * out[1::2]
+
+    def combine(self, coeffs, vecs):
+        cf = np.asarray(coeffs, dtype=np.complex128)
+        parts = [v[0] for v in vecs] + [v[1] for v in vecs]
+        re = self.r.combine(np.concatenate([cf.real, -cf.imag]), parts)
+        im = self.r.combine(np.concatenate([cf.imag, cf.real]), parts)
+        return (re, im)
+
 
 def _fgmres(ops, matvec, v0, m, atol, cs):
     """Inner Arnoldi process: A [v_0..v_j] = C B + V H with H held as Q R.
@@ -137,15 +171,12 @@ def _fgmres(ops, matvec, v0, m, atol, cs):
     for j in range(m):
         w = matvec(vs[-1])
         w_norm = ops.nrm2(w)
-        for i, c in enumerate(cs):                     # (1 - C C^T) A : project out the recycle space
-            alpha = ops.dot(c, w)
-            B[i, j] = alpha
-            ops.axpy(-alpha, c, w)
+        # (1 - C C^H) A, then modified Gram-Schmidt against V: one sequential sweep over the
+        # columns of [C, V], dot and update per column in that order, coefficients back at the end
+        coef = ops.mgs_project(list(cs) + vs, w)
+        B[:, j] = coef[:len(cs)]
         hcur = np.zeros(j + 2, dtype=dt)
-        for i, v in enumerate(vs):                     # modified Gram-Schmidt against V
-            alpha = ops.dot(v, w)
-            hcur[i] = alpha
-            ops.axpy(-alpha, v, w)
+        hcur[:len(vs)] = coef[len(cs):]
         hcur[j + 1] = ops.nrm2(w)
         with np.errstate(over="ignore", divide="ignore"):
             alpha = 1 / hcur[-1].real
@@ -218,17 +249,11 @@ def gcrotmk_device(ctx, matvec, b, n, rtol=1e-5, atol=0.0, maxiter=1000, m=20, k
         except np.linalg.LinAlgError:
             break
         # new outer pair: ux = (Z - U B) y, cx = V H y, normalised so that cx = A ux, |cx| = 1
-        ux = ops.scaled(y[0], vs[0])
-        for z, yc in zip(vs[1:], y[1:]):
-            ops.axpy(yc, z, ux)
         by = B.dot(y)
-        for (c, u), byc in zip(CU, by):
-            ops.axpy(-byc, u, ux)
+        ux = ops.combine(np.concatenate([y, -by]), vs[:len(y)] + [u for c, u in CU])
         with np.errstate(invalid="ignore"):
             hy = Q.dot(R.dot(y))
-        cx = ops.scaled(hy[0], vs[0])
-        for v, hyc in zip(vs[1:], hy[1:]):
-            ops.axpy(hyc, v, cx)
+        cx = ops.combine(hy, vs[:len(hy)])
         try:
             alpha = 1 / ops.nrm2(cx)
             if not np.isfinite(alpha):

@@ -100,6 +100,17 @@ int hipeig_orthonormalize(hipeig_ctx* ctx, int64_t n, int m, const double* const
                           double* x, double lindep, int method, double* innerprod,
                           int* is_lindep);
 
+/* Sequential modified Gram-Schmidt projection, coefficients returned: for j = 0..m-1:
+ * coeffs[j] = <V_j, w>; w -= coeffs[j]*V_j.  This is the Arnoldi orthogonalisation inside
+ * scipy's gcrotmk/_fgmres, i.e. the inner loop of NumpyVector.solve with linearSolver="gcrotmk"
+ * (numpyVector.py:161); no host round trip between columns.  The pair form treats (re, im)
+ * buffer pairs as complex vectors with the conjugated product (complex contour solves of
+ * feast.py:90); coeffs then holds m (re, im) pairs.                                       */
+int hipeig_mgs_project(hipeig_ctx* ctx, int64_t n, int m, const double* const* V, double* w,
+                       double* coeffs);
+int hipeig_pair_mgs_project(hipeig_ctx* ctx, int64_t n, int m, const double* const* Vre,
+                            const double* const* Vim, double* wre, double* wim, double* coeffs);
+
 /* ---- sparse operator: replaces the scipy.sparse / ndarray H handed to the loop ----- */
 /* Host CSR -> device.  rowptr has nrows+1 entries (local rows), col holds GLOBAL column
  * indices in [0, ncols).  Rows may be empty or unsorted; duplicates are summed by the
