@@ -110,11 +110,12 @@ def main():
         json.dump(rep, open(out, "w"), indent=1)
 
     with contextlib.redirect_stdout(sys.stderr):
-        rep["config2_single_vector"], rep["config3_block8"] = config2_3()
-        save()
-        rep["config1_dense_plumbing"] = config1()
-        save()
-        if "--feast" in sys.argv:                 # slow for now: complex solves are host-orchestrated pair arithmetic
+        if "--only-feast" not in sys.argv:
+            rep["config2_single_vector"], rep["config3_block8"] = config2_3()
+            save()
+            rep["config1_dense_plumbing"] = config1()
+            save()
+        if "--feast" in sys.argv or "--only-feast" in sys.argv:                 # slow for now: complex solves are host-orchestrated pair arithmetic
             rep["config5_feast"] = config5()
             save()
     print(json.dumps(rep))
