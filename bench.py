@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--n", "--size", dest="n", type=int, default=10_000_000)
     ap.add_argument("--nnz-row", type=int, default=64)
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--sigma", type=float, default=0.02)
@@ -53,7 +53,7 @@ def global_bytes(N, nnz):
     return nnz * 12 + (N + 1) * 4 + 8 * N + 8 * N
 
 
-def main():
+def main(result):
     a = parse()
     import numpy as np
     import eigensolvers_amd as ea
@@ -63,14 +63,15 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     dist = None
-    if world > 1:
+    force = os.environ.get("HIPEIG_FORCE_COLLECTIVES", "0") not in ("", "0")     # rehearse the RCCL path on one rank
+    if world > 1 or force:
         dist = D.init_process_group_gloo()
     try:
         ctx = ea.HipContext(local_rank)
     except ea._lib.HipEigError:                      # launcher already narrowed the visible devices to one
         ctx = ea.HipContext(0)
     ea.HipContext._default = ctx
-    if world > 1:
+    if world > 1 or force:
         D.attach_rccl(ctx)
 
     def barrier():
@@ -200,11 +201,18 @@ def main():
                                "host_cpus": os.cpu_count(), "blas_threads": blas,
                                "numpy": np.__version__, "scipy": __import__("scipy").__version__}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        result["line"] = json.dumps(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    # Native libraries (gloo, RCCL) write banners to file descriptor 1; keep stdout to the one JSON
+    # line by running everything with fd 1 pointed at stderr and printing the result afterwards.
+    from eigensolvers_amd.distributed import stdout_to_stderr
+    _result = {}
+    with stdout_to_stderr():
+        main(_result)
+    if "line" in _result:
+        print(_result["line"], flush=True)

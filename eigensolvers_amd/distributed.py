@@ -8,7 +8,24 @@ side only has to (a) agree on the row ranges and (b) distribute RCCL's 128-byte 
 which is done here over ``torch.distributed`` (gloo) - torch is plumbing for the
 rendezvous, no tensor of the hot path ever goes through it.
 """
+import contextlib
 import os
+import sys
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """Send everything written to file descriptor 1 to stderr for the duration (gloo and RCCL
+    print banners to stdout from native code; a benchmark's stdout must stay machine-readable)."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def row_range(N, nranks, rank):
@@ -35,7 +52,8 @@ def init_process_group_gloo():
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="gloo")
+        with stdout_to_stderr():
+            dist.init_process_group(backend="gloo")
     return dist
 
 
@@ -54,7 +72,8 @@ def attach_rccl(ctx):
     """Create the RCCL communicator of ``ctx`` for the current gloo group (collective)."""
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
-    uid = ctx.new_unique_id() if rank == 0 else b"\0" * 128
-    uid = broadcast_bytes(uid, 128, src=0)
-    ctx.attach_comm(world, rank, uid)
+    with stdout_to_stderr():
+        uid = ctx.new_unique_id() if rank == 0 else b"\0" * 128
+        uid = broadcast_bytes(uid, 128, src=0)
+        ctx.attach_comm(world, rank, uid)
     return rank, world
