@@ -84,6 +84,9 @@ extern "C" int hipeig_comm_init(hipeig_ctx* c, int nranks, int rank, const void*
   // communicator, so the RCCL plumbing can be exercised on a single-GPU box.
   const char* force = getenv("HIPEIG_FORCE_COLLECTIVES");
   c->collectives = (nranks > 1) || (force && atoi(force) != 0);
+  // HIPEIG_OVERLAP=0 turns the all-gather / local-window overlap off (default on)
+  const char* ov = getenv("HIPEIG_OVERLAP");
+  c->overlap = c->collectives && !(ov && atoi(ov) == 0);
   c->row_counts = (int64_t*)calloc((size_t)nranks, sizeof(int64_t));
   return 0;
 }
@@ -152,6 +155,28 @@ int hipeig_allgather_x(hipeig_ctx* c, const double* x_local, int64_t n_local, in
                               hipMemcpyDeviceToDevice, c->stream));
   RCCL_CHECK(g_rccl.AllGather(mine, c->x_full, (size_t)stride, NCCL_FLOAT64,
                               (ncclComm_t)c->comm, c->stream));
+  *x_full_out = c->x_full;
+  return 0;
+}
+
+// Split form of the operand all-gather: `begin` issues the copy + ncclAllGather on the
+// communication stream (ordered after everything already queued on the compute stream),
+// `end` makes the compute stream wait for it.  Between the two the caller may launch work that
+// reads only x_local.
+int hipeig_allgather_x_begin(hipeig_ctx* c, const double* x_local, int64_t n_local, int64_t stride) {
+  HIPEIG_REQUIRE(c->collectives, "no communicator");
+  HIPEIG_REQUIRE(stride >= n_local && stride * c->nranks <= c->x_full_n, "operand buffer smaller than the partition");
+  double* mine = c->x_full + (int64_t)c->rank * stride;
+  HIPEIG_CHECK(hipEventRecord(c->ev_x, c->stream));
+  HIPEIG_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_x, 0));
+  HIPEIG_CHECK(hipMemcpyAsync(mine, x_local, (size_t)n_local * sizeof(double), hipMemcpyDeviceToDevice, c->comm_stream));
+  RCCL_CHECK(g_rccl.AllGather(mine, c->x_full, (size_t)stride, NCCL_FLOAT64, (ncclComm_t)c->comm, c->comm_stream));
+  HIPEIG_CHECK(hipEventRecord(c->ev_comm, c->comm_stream));
+  return 0;
+}
+
+int hipeig_allgather_x_end(hipeig_ctx* c, const double** x_full_out) {
+  HIPEIG_CHECK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
   *x_full_out = c->x_full;
   return 0;
 }

@@ -50,7 +50,7 @@ struct hipeig_ctx {
   int num_cu;
   hipStream_t stream;        // compute
   hipStream_t comm_stream;   // collectives / copies overlapped with compute
-  hipEvent_t ev0, ev1, ev_comm;
+  hipEvent_t ev0, ev1, ev_comm, ev_x;
   // reduction workspace
   double* d_partials;        // HIPEIG_MAX_PARTIALS * (HIPEIG_MAX_COLS*HIPEIG_MAX_COLS) doubles
   size_t partials_doubles;
@@ -72,6 +72,9 @@ struct hipeig_ctx {
   double* x_full;            // all-gathered operand of the operator
   int64_t x_full_n;
   int64_t* row_counts;       // rows per rank (host), length nranks
+  int overlap;               // 1: all-gather on the comm stream while the local-column windows are swept
+  double* ytmp;              // raw partial sums handed from the local-window launch to the remote one
+  int64_t ytmp_n;
 };
 
 struct hipeig_csr {
@@ -105,6 +108,8 @@ int hipeig_comm_setup_rows(hipeig_ctx* ctx, int64_t nrows_local, int64_t* stride
 int hipeig_allreduce_sum(hipeig_ctx* ctx, double* d_buf, int count);
 int hipeig_allgather_x(hipeig_ctx* ctx, const double* x_local, int64_t n_local, int64_t stride,
                        const double** x_full_out);
+int hipeig_allgather_x_begin(hipeig_ctx* ctx, const double* x_local, int64_t n_local, int64_t stride);
+int hipeig_allgather_x_end(hipeig_ctx* ctx, const double** x_full_out);
 
 // ---- device helpers ------------------------------------------------------------------
 // Separately rounded multiply / add.  hipcc contracts a*b+c into an FMA by default and the

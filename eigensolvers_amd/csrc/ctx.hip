@@ -30,6 +30,7 @@ extern "C" int hipeig_ctx_create(int device, hipeig_ctx** out) {
   HIPEIG_CHECK(hipEventCreate(&c->ev0));
   HIPEIG_CHECK(hipEventCreate(&c->ev1));
   HIPEIG_CHECK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
+  HIPEIG_CHECK(hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming));
   c->partials_doubles = (size_t)HIPEIG_MAX_PARTIALS * HIPEIG_MAX_COLS * HIPEIG_MAX_COLS;
   HIPEIG_CHECK(hipMalloc((void**)&c->d_partials, c->partials_doubles * sizeof(double)));
   c->scalars_doubles = 4096;
@@ -64,10 +65,12 @@ extern "C" int hipeig_ctx_destroy(hipeig_ctx* c) {
   hipHostFree(c->h_mr_state);
   if (c->mr_ws) hipFree(c->mr_ws);
   if (c->x_full) hipFree(c->x_full);
+  if (c->ytmp) hipFree(c->ytmp);
   free(c->row_counts);
   hipEventDestroy(c->ev0);
   hipEventDestroy(c->ev1);
   hipEventDestroy(c->ev_comm);
+  hipEventDestroy(c->ev_x);
   hipStreamDestroy(c->stream);
   hipStreamDestroy(c->comm_stream);
   free(c);

@@ -19,6 +19,7 @@ CsrView hipeig_csr_view(const hipeig_csr* A);
 TcooView hipeig_tcoo_view(const hipeig_csr* A);
 TcooView hipeig_tcoow_view(const hipeig_csr* A);
 size_t hipeig_tcoow_lds_bytes(const hipeig_csr* A);
+int hipeig_tcoow_overlap_begin(hipeig_ctx* c, hipeig_csr* A, const double* x_local, TcooView* tv2, const double** xg);
 int hipeig_spmv_grid(const hipeig_csr* A, int variant);
 int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A);
 size_t hipeig_tcoo_lds_bytes(const hipeig_csr* A);
@@ -295,9 +296,14 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
       double* w1 = W[(k + 1) % 3];
       double* w2 = W[(k + 2) % 3];
       const double* xg = nullptr;
-      if (hipeig_allgather_x(c, r2, n, A->col_stride, &xg)) return 4;
+      TcooView tv = tview;
+      int ov = 0;
       if (variant == 4) {
-        TcooView tv = tview;
+        ov = hipeig_tcoow_overlap_begin(c, A, r2, &tv, &xg);      // local windows under the all-gather
+        if (ov < 0) return 4;
+      }
+      if (ov == 0 && hipeig_allgather_x(c, r2, n, A->col_stride, &xg)) return 4;
+      if (variant == 4) {
         for (int sw = 0; sw < nsweepA; ++sw) {
           tv.unit_begin = sw * gA;
           hipLaunchKernelGGL((minres_ka_kernel<4>), dim3(gA), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, view, tv, xg, a, V + 0, V + 1, r2, r1, yb, pA + sw * gA);

@@ -57,6 +57,7 @@ TcooView hipeig_tcoow_view(const hipeig_csr* A) {
   if (const char* e = getenv("HIPEIG_TCOO_ABLATE")) t.ablate = atoi(e);   // timing experiments (wrong results)
   t.nrows = A->nrows;
   t.gather_len = A->gather_len;
+  t.win_lo = 0; t.win_hi = A->w_nwin; t.invert = 0; t.yinit = nullptr; t.raw_out = nullptr;
   return t;
 }
 
@@ -70,6 +71,7 @@ TcooView hipeig_tcoo_view(const hipeig_csr* A) {
   if (const char* e = getenv("HIPEIG_TCOO_ABLATE")) t.ablate = atoi(e);   // timing experiments (wrong results)
   t.nrows = A->nrows;
   t.gather_len = A->gather_len;
+  t.win_lo = 0; t.win_hi = A->t_nwin; t.invert = 0; t.yinit = nullptr; t.raw_out = nullptr;
   return t;
 }
 
@@ -105,10 +107,67 @@ int hipeig_spmv_grid(const hipeig_csr* A, int variant) {
   return (int)g;
 }
 
+// Multi-GPU overlap for the TCOO-W layout.  The windows that lie entirely inside this rank's own
+// column range need only x_local, so they are swept while the all-gather of the other ranks'
+// slices runs on the communication stream; the raw partial sums go to ctx->ytmp.  The caller then
+// launches the remaining windows (`tv2`: inverted window range, accumulators started from ytmp)
+// with its own epilogue.  Returns 1 when the split path was taken (tv2 / xg set), 0 when the
+// caller should use the plain all-gather + full sweep, -1 on error.
+int hipeig_tcoow_overlap_begin(hipeig_ctx* c, hipeig_csr* A, const double* x_local, TcooView* tv2, const double** xg) {
+  if (!c->collectives || !c->overlap || !A->w_idx || A->col_stride <= 0) return 0;
+  const int64_t lo = (int64_t)c->rank * A->col_stride, hi = lo + A->nrows;
+  const int64_t W = (int64_t)1 << A->w_wbits;
+  const int cl0 = (int)((lo + W - 1) >> A->w_wbits), cl1 = (int)(hi >> A->w_wbits);
+  if (cl1 <= cl0) return 0;                             // no window is entirely local
+  if (c->ytmp_n < A->nrows) {
+    if (c->ytmp) { if (hipFree(c->ytmp) != hipSuccess) return -1; }
+    c->ytmp = nullptr; c->ytmp_n = 0;
+    if (hipMalloc((void**)&c->ytmp, (size_t)A->nrows * sizeof(double)) != hipSuccess) {
+      hipeig_set_error("out of device memory for the overlap buffer");
+      return -1;
+    }
+    c->ytmp_n = A->nrows;
+  }
+  if (hipeig_allgather_x_begin(c, x_local, A->nrows, A->col_stride)) return -1;
+  TcooView t = hipeig_tcoow_view(A);
+  t.win_lo = cl0; t.win_hi = cl1; t.invert = 0; t.yinit = nullptr; t.raw_out = c->ytmp;
+  const int g = hipeig_spmv_grid(A, 4);
+  AxpyEpilogue none{0.0, 0.0, nullptr, nullptr};
+  for (int ub = 0; ub < A->w_nunits; ub += g) {
+    t.unit_begin = ub;
+    // x_local - lo: global column j of the local range is x_local[j - lo]
+    hipLaunchKernelGGL(spmv_tcoow_kernel, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t, x_local - lo, none);
+  }
+  if (hipGetLastError() != hipSuccess) { hipeig_set_error("local-window launch failed"); return -1; }
+  if (hipeig_allgather_x_end(c, xg)) return -1;
+  *tv2 = hipeig_tcoow_view(A);
+  tv2->win_lo = cl0; tv2->win_hi = cl1; tv2->invert = 1; tv2->yinit = c->ytmp; tv2->raw_out = nullptr;
+  return 1;
+}
+
 static int launch_spmv(hipeig_ctx* c, hipeig_csr* A, double a_self, double a_sum,
                        const double* x, double* y) {
   if (A->nrows == 0) return 0;
   const double* xg = nullptr;
+  {
+    const int variant0 = hipeig_csr_pick_variant(c, A);
+    if (variant0 < 0) return 1;
+    if (variant0 == 4) {
+      TcooView t2;
+      const int ov = hipeig_tcoow_overlap_begin(c, A, x, &t2, &xg);
+      if (ov < 0) return 4;
+      if (ov == 1) {
+        AxpyEpilogue epi2{a_self, a_sum, x, y};
+        const int g = hipeig_spmv_grid(A, 4);
+        for (int ub = 0; ub < A->w_nunits; ub += g) {
+          t2.unit_begin = ub;
+          hipLaunchKernelGGL(spmv_tcoow_kernel, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t2, xg, epi2);
+        }
+        HIPEIG_CHECK(hipGetLastError());
+        return 0;
+      }
+    }
+  }
   if (hipeig_allgather_x(c, x, A->nrows, A->col_stride, &xg)) return 4;
   // shift term: x restricted to this operator's rows.  Partitioned run: x IS that slice; a row
   // slab applied to a full-length operand (single process): the slice starts at row_offset.

@@ -148,6 +148,12 @@ struct TcooView {
   int32_t ablate;                        // timing experiments only: 1 = skip gathers, 2 = skip LDS adds,
                                          // 4 = skip the value stream, 8 = gather from window 0 only
   int64_t nrows, gather_len;
+  // split sweeps (multi-GPU overlap): process the windows inside [win_lo, win_hi) - or, with
+  // `invert`, the windows outside it; start the accumulators from yinit instead of zero;
+  // store raw sums to raw_out instead of running the epilogue.  Defaults: all windows, 0, no.
+  int32_t win_lo, win_hi, invert;
+  const double* yinit;
+  double* raw_out;
 };
 
 __device__ __forceinline__ void lds_add_f64(double* p, double v) {
@@ -282,23 +288,24 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
   const int u = T.unit_begin + blockIdx.x;
   if (u >= T.nunits) return;                         // uniform for the workgroup
   uint32_t* offL = reinterpret_cast<uint32_t*>(yacc + T.rw);     // this unit's window offsets
-  for (int k = threadIdx.x; k < T.rw; k += blockDim.x) yacc[k] = 0.0;
+  const int64_t r0 = (int64_t)u * T.rw;
+  for (int k = threadIdx.x; k < T.rw; k += blockDim.x)
+    yacc[k] = (T.yinit && r0 + k < T.nrows) ? T.yinit[r0 + k] : 0.0;
   for (int k = threadIdx.x; k <= T.nwin; k += blockDim.x) offL[k] = T.off[(size_t)u * T.nwin + k];
   __syncthreads();
   // The unit's non-zeros are ONE contiguous stream (window after window).  Waves take
   // batches of 64*TCOO_UNROLL round-robin; each lane tracks the window of its elements by
   // walking the offsets (they only move forward), so a batch may straddle windows and the
   // stream loads of batch k+1 are in flight while batch k gathers and scatters.
-  const uint32_t uend = offL[T.nwin];
   const uint32_t step = (uint32_t)nw * 64 * TCOO_UNROLL;
 #if TCOOW_INTERLEAVE
   // element j of a batch: the 16 waves cover adjacent 64-element groups at every j, so the
   // whole CU works on one narrow column range at a time (L1 reuse across waves)
   const uint32_t jstride = (uint32_t)nw * 64;
-  uint32_t base = offL[0] + (uint32_t)wid * 64;
+  const uint32_t wave_off = (uint32_t)wid * 64;
 #else
   const uint32_t jstride = 64;
-  uint32_t base = offL[0] + (uint32_t)wid * 64 * TCOO_UNROLL;
+  const uint32_t wave_off = (uint32_t)wid * 64 * TCOO_UNROLL;
 #endif
   int c = 0;
   double sink = 0.0;
@@ -307,7 +314,7 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
 #define TCOO_LOAD(ID, V, BASE)                                                         \
   _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j) {                            \
     const uint32_t q = (BASE) + lane + jstride * j;                                         \
-    const bool ok = q < uend;                                                          \
+    const bool ok = q < send;                                                          \
     ID[j] = ok ? __builtin_nontemporal_load(T.idx + q) : 0xFFFFFFFFu;                  \
     V[j] = (ok && !(TCOO_ABL(T, 4))) ? __builtin_nontemporal_load(T.val + q) : 1.0;     \
   }
@@ -330,26 +337,36 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
       _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j) sink += V[j] + (double)ID[j]; \
     }                                                                                  \
   }
-  if (base < uend) {
-    TCOO_LOAD(idA, vA, base)
-    while (true) {
-      const uint32_t nb = base + step;
-      const bool more = nb < uend;                   // uniform per wave
-      if (more) { TCOO_LOAD(idB, vB, nb) }
-      TCOO_CONSUME(idA, vA, base)
-      if (!more) break;
-      const uint32_t nb2 = nb + step;
-      const bool more2 = nb2 < uend;
-      if (more2) { TCOO_LOAD(idA, vA, nb2) }
-      TCOO_CONSUME(idB, vB, nb)
-      if (!more2) break;
-      base = nb2;
+  // stream ranges of this launch: all windows, the windows in [win_lo, win_hi), or those outside
+  const int nparts = T.invert ? 2 : 1;
+  for (int part = 0; part < nparts; ++part) {
+    const uint32_t sbeg = T.invert ? (part == 0 ? offL[0] : offL[T.win_hi]) : offL[T.win_lo];
+    const uint32_t send = T.invert ? (part == 0 ? offL[T.win_lo] : offL[T.nwin]) : offL[T.win_hi];
+    uint32_t base = sbeg + wave_off;
+    if (base < send) {
+      TCOO_LOAD(idA, vA, base)
+      while (true) {
+        const uint32_t nb = base + step;
+        const bool more = nb < send;                 // uniform per wave
+        if (more) { TCOO_LOAD(idB, vB, nb) }
+        TCOO_CONSUME(idA, vA, base)
+        if (!more) break;
+        const uint32_t nb2 = nb + step;
+        const bool more2 = nb2 < send;
+        if (more2) { TCOO_LOAD(idA, vA, nb2) }
+        TCOO_CONSUME(idB, vB, nb)
+        if (!more2) break;
+        base = nb2;
+      }
     }
   }
 #undef TCOO_LOAD
 #undef TCOO_CONSUME
   asm volatile("" ::"v"(sink));
   __syncthreads();
-  const int64_t r0 = (int64_t)u * T.rw;
-  for (int k = threadIdx.x; k < T.rw && r0 + k < T.nrows; k += blockDim.x) epi.row(r0 + k, yacc[k], acc);
+  if (T.raw_out) {
+    for (int k = threadIdx.x; k < T.rw && r0 + k < T.nrows; k += blockDim.x) T.raw_out[r0 + k] = yacc[k];
+  } else {
+    for (int k = threadIdx.x; k < T.rw && r0 + k < T.nrows; k += blockDim.x) epi.row(r0 + k, yacc[k], acc);
+  }
 }

@@ -37,6 +37,21 @@ opts = {"linearSystemArgs": {"linearSolver": "minres", "linearIter": 2000, "line
 ev, Y, st = ea.inexactLanczosDiagonalization(H, ea.HipVector(guess_vector(N, 1).copy(), opts, ctx=ctx),
                                              0.02, 8, 10, 1e-13, writeOut=False)
 out.update(ev0=float(ev[0]), cumIter=int(st["cumIter"]), conv=bool(st["isConverged"]))
+# a larger operator (3 column windows): the all-gather overlaps the local-window launch, the remaining
+# window is swept afterwards from the gathered operand; compare with the unsplit CSR-stream kernel
+N2 = 300000
+H2 = ea.HipCsrOperator.generate(N2, 32, seed=5, ctx=ctx)
+x2 = ea.HipVector(np.random.default_rng(4).standard_normal(N2), ctx=ctx)
+H2.set_variant(2); y_ref = x2.applyOp(H2)
+H2.set_variant(4); y_ov = x2.applyOp(H2)
+d = ea.HipVector.linearCombination([y_ov, y_ref], [1.0, -1.0])
+out["overlap_spmv_rel"] = d.norm() / y_ref.norm()
+b2 = ea.HipVector(guess_vector(N2, 2).copy(), opts, ctx=ctx); b2.normalize()
+w4 = ea.HipVector.solve(H2, b2, 0.02); it4 = w4.last_solve_stats["iterations"]
+H2.set_variant(2)
+w2 = ea.HipVector.solve(H2, b2, 0.02); it2 = w2.last_solve_stats["iterations"]
+d = ea.HipVector.linearCombination([w4, w2], [1.0, -1.0])
+out.update(overlap_minres_rel=d.norm() / w2.norm(), it4=it4, it2=it2)
 print("RESULT " + json.dumps(out))
 """
 
@@ -53,3 +68,5 @@ def test_forced_collectives_single_rank():
     g = load_golden("gapped_csr_n4000_minres.npz")
     assert abs(r["ev0"] - g["ev"][0]) <= 1e-10 * abs(g["ev"][0])
     assert r["cumIter"] == int(g["cumIter"]) and r["conv"]
+    assert r["overlap_spmv_rel"] < 1e-14
+    assert r["it4"] == r["it2"] and r["overlap_minres_rel"] < 1e-8
