@@ -4,7 +4,6 @@ HipVector), against the CPU oracle and the golden vectors of the real reference.
 Tolerances (fp64 path, stated per test): element-wise kernels 1e-15..1e-14 relative;
 reductions 1e-13 relative to sum|a_i b_i|; inner solves 1e-9 relative to ||x||; Ritz values
 1e-10 relative (the north-star bound); iteration counts equal."""
-import ctypes as C
 import warnings
 
 import numpy as np
@@ -13,7 +12,7 @@ import scipy.linalg as la
 import scipy.sparse as sp
 
 from conftest import load_golden
-from eigensolvers_amd.generators import dense_test_matrix, gapped_csr_host, guess_vector
+from eigensolvers_amd.generators import dense_test_matrix, gapped_csr_host
 from oracle import lanczos_ref
 from oracle.minres_ref import minres as minres_ref
 from oracle.numpy_vector import RefVector

@@ -13,7 +13,6 @@ from conftest import load_golden
 from eigensolvers_amd import subspace
 from eigensolvers_amd.distributed import all_row_ranges, row_range
 from eigensolvers_amd.generators import dense_test_matrix, gapped_csr_host, gapped_params
-from oracle import lanczos_ref
 from oracle.numpy_vector import RefVector
 
 ea.AbstractVector.register(RefVector)

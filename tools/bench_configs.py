@@ -27,7 +27,7 @@ import scipy.linalg as la
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import eigensolvers_amd as ea  # noqa: E402
-from eigensolvers_amd.generators import gapped_csr_host, guess_vector  # noqa: E402
+from eigensolvers_amd.generators import guess_vector  # noqa: E402
 
 
 def timed(fn):
