@@ -323,6 +323,16 @@ def test_full_size_operator_properties(hip):
     # rows 400000..400500 against the host generator's slab
     slab = gapped_csr_host(N, 32, seed=7, row_begin=400000, row_end=400500)
     _within(HX.array[400000:400500], slab @ x, 1e-13 * (np.abs(slab) @ np.abs(x)))
+    # reproducibility: variants 1-3 fix the summation order (bitwise equal runs); variant 4 adds a row
+    # from several waves, so two runs may differ in the last bits only
+    for variant, bitwise in ((2, True), (3, True), (4, False)):
+        H.set_variant(variant)
+        r1, r2 = X.applyOp(H).array, X.applyOp(H).array
+        if bitwise:
+            assert np.array_equal(r1, r2)
+        else:
+            assert np.max(np.abs(r1 - r2)) <= 1e-15 * np.max(np.abs(r1)) * 8
+    assert X.vdot(Y) == X.vdot(Y) and X.norm() == X.norm()          # reductions: fixed tree
     # two operators with different LDS footprints used alternately (kernel attributes are global)
     small_h = gapped_csr_host(4000, 32, seed=7)
     small = hip.HipCsrOperator.from_scipy(small_h)
