@@ -62,6 +62,7 @@ SIGNATURES = {
     "hipeig_csr_set_variant": [_P, C.c_int],
     "hipeig_spmv": [_P, _P, _P, _P],
     "hipeig_spmv_shift": [_P, _P, _D, _D, _P, _P],
+    "hipeig_spmm": [_P, _P, C.c_int, _PP, _PP],
     "hipeig_minres": [_P, _P, _D, _D, _P, _P, _D, C.c_int, _IP, _DP],
     "hipeig_timer_start": [_P],
     "hipeig_timer_stop": [_P, C.POINTER(C.c_float)],

@@ -72,6 +72,8 @@ struct hipeig_ctx {
   double* x_full;            // all-gathered operand of the operator
   int64_t x_full_n;
   int64_t* row_counts;       // rows per rank (host), length nranks
+  double* blk_ws;            // interleaved operand / result blocks of hipeig_spmm
+  size_t blk_ws_doubles;
   int overlap;               // 1: all-gather on the comm stream while the local-column windows are swept
   double* ytmp;              // raw partial sums handed from the local-window launch to the remote one
   int64_t ytmp_n;

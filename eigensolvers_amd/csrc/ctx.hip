@@ -66,6 +66,7 @@ extern "C" int hipeig_ctx_destroy(hipeig_ctx* c) {
   if (c->mr_ws) hipFree(c->mr_ws);
   if (c->x_full) hipFree(c->x_full);
   if (c->ytmp) hipFree(c->ytmp);
+  if (c->blk_ws) hipFree(c->blk_ws);
   free(c->row_counts);
   hipEventDestroy(c->ev0);
   hipEventDestroy(c->ev1);

@@ -217,6 +217,14 @@ class HipCsrOperator:
     def apply(self, x, y):
         _lib.call("hipeig_spmv", self.ctx.handle, self.handle, x.ptr, y.ptr)
 
+    def apply_block(self, xs):
+        """[H x for x in xs] as one block product (tall-skinny SpMM); xs are DeviceBuffers."""
+        ys = [self.ctx.alloc(self.nrows) for _ in xs]
+        xt, keep1 = _ptr_table(xs)
+        yt, keep2 = _ptr_table(ys)
+        _lib.call("hipeig_spmm", self.ctx.handle, self.handle, len(xs), xt, yt)
+        return ys
+
     def apply_shifted(self, sigma, x, y, reverse=False):
         _lib.call("hipeig_spmv_shift", self.ctx.handle, self.handle, float(sigma),
                   -1.0 if reverse else 1.0, x.ptr, y.ptr)
@@ -490,11 +498,16 @@ class HipVector(AbstractVector):
 
     @staticmethod
     def matrixRepresentation(operator, vectors):
+        if not isinstance(operator, HipCsrOperator):
+            raise TypeError("HipVector.matrixRepresentation needs a HipCsrOperator (device-resident CSR)")
         m = len(vectors)
+        v0 = vectors[0]
+        # all kets H y_j in one block product, then one Gram block <y_i, H y_j> on the matrix cores
+        kets = operator.apply_block([v._buf for v in vectors])
         M = np.empty((m, m), dtype=np.float64)
-        for j in range(m):
-            ket = vectors[j].applyOp(operator)
-            M[:, j] = HipVector._multi_dot(vectors, ket)
+        ta, keep1 = _ptr_table([v._buf for v in vectors])
+        tb, keep2 = _ptr_table(kets)
+        _lib.call("hipeig_gram", v0.ctx.handle, v0._buf.n, m, ta, m, tb, M.ctypes.data_as(C.POINTER(C.c_double)))
         return np.tril(M) + np.tril(M, -1).T           # lower triangle mirrored, numpyVector.py:186-189
 
     @staticmethod

@@ -143,6 +143,11 @@ int hipeig_spmv(hipeig_ctx* ctx, hipeig_csr* A, const double* x, double* y);
 int hipeig_spmv_shift(hipeig_ctx* ctx, hipeig_csr* A, double sigma, double sign,
                       const double* x, double* y);
 
+/* The k applications of matrixRepresentation (numpyVector.py:184-185) as ONE block product:
+ * Y[j] = H X[j], j < k.  Internally the operands are interleaved so that each non-zero costs
+ * one index fetch and one contiguous gather for all k (tall-skinny SpMM).                   */
+int hipeig_spmm(hipeig_ctx* ctx, hipeig_csr* A, int k, const double* const* X, double* const* Y);
+
 /* ---- inner linear solve: NumpyVector.solve with linearSolver="minres" (:147-178) ---- */
 /* Solves sign*(sigma*I - H) x = b from a zero initial guess with the Paige-Saunders
  * MINRES recurrences in the evaluation order of scipy.sparse.linalg.minres (the call at

@@ -120,6 +120,26 @@ def test_vector_ops_match_reference_golden(hip, gapped4000):
                                gm["lincomb"], rtol=0, atol=1e-14)
 
 
+def test_block_product_matches_single_products(hip, gapped4000):
+    """hipeig_spmm (interleaved tall-skinny SpMM) against k separate products, k = 1..20."""
+    Hh, _ = gapped4000
+    H = hip.HipCsrOperator.from_scipy(Hh)
+    rng = np.random.default_rng(3)
+    for k in (1, 3, 8, 11, 16, 20):
+        Xh = rng.standard_normal((4000, k))
+        X = [hip.HipVector(Xh[:, j].copy()) for j in range(k)]
+        Y = H.apply_block([x._buf for x in X])
+        ref = Hh @ Xh
+        bound = 1e-14 * (np.abs(Hh) @ np.abs(Xh))
+        for j in range(k):
+            _within(hip.HipVector(Y[j]).array, ref[:, j], bound[:, j])
+    vecs = [hip.HipVector(rng.standard_normal(4000)) for _ in range(19)]
+    M = hip.HipVector.matrixRepresentation(H, vecs)
+    Vh = np.column_stack([v.array for v in vecs])
+    _within(M, Vh.T @ (Hh @ Vh), 1e-11)
+    assert np.array_equal(M, M.T)
+
+
 # ---------------------------------------------------------------- operator edge cases
 def test_spmv_ragged_empty_long_and_unsorted_rows(hip):
     rng = np.random.default_rng(5)
