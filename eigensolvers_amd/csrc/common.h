@@ -60,9 +60,15 @@ struct hipeig_ctx {
   const double** d_ptrs;     // device pointer tables for tall-skinny kernels
   const double** h_ptrs;     // pinned staging of the same
   size_t ptrs_count;
-  // MINRES workspace (6 vectors) cached across solves
+  // MINRES workspace (7 vectors: r1 r2 y, w1 w2 w, x) cached across solves
   double* mr_ws;
   int64_t mr_ws_n;
+  // hipGraph of one 18-iteration MINRES chunk, replayed while its key (operator layout, shift,
+  // tolerances, workspace) is unchanged
+  hipGraphExec_t mr_graph;
+  void* mr_graph_key;        // malloc'ed copy of the key the graph was captured for
+  size_t mr_graph_key_bytes;
+  int use_graph;             // HIPEIG_GRAPH (default 1)
   MinresState* d_mr_state;   // ring of 3
   MinresState* h_mr_state;   // pinned
   // distributed

@@ -46,6 +46,8 @@ extern "C" int hipeig_ctx_create(int device, hipeig_ctx** out) {
                              hipHostMallocDefault));
   c->nranks = 1;
   c->rank = 0;
+  const char* g = getenv("HIPEIG_GRAPH");
+  c->use_graph = g ? atoi(g) : 1;
   *out = c;
   return 0;
 }
@@ -63,6 +65,8 @@ extern "C" int hipeig_ctx_destroy(hipeig_ctx* c) {
   hipHostFree(c->h_ptrs);
   hipFree(c->d_mr_state);
   hipHostFree(c->h_mr_state);
+  if (c->mr_graph) hipGraphExecDestroy(c->mr_graph);
+  free(c->mr_graph_key);
   if (c->mr_ws) hipFree(c->mr_ws);
   if (c->x_full) hipFree(c->x_full);
   if (c->ytmp) hipFree(c->ytmp);

@@ -228,24 +228,26 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   HIPEIG_REQUIRE(c->collectives || A->nrows == A->ncols, "the inner solve needs a square operator (or a row partition)");
   *info = 0;
   if (out_stats) memset(out_stats, 0, 8 * sizeof(double));
-  if (hipeig_vec_fill(c, x, n, 0.0)) return 1;
   double bb = 0.0;
   if (hipeig_dot(c, n, b, b, &bb)) return 1;
-  if (bb == 0.0) return 0;            // beta1 == 0: the exact solution is x0 = 0
+  if (bb == 0.0) return hipeig_vec_fill(c, x, n, 0.0);            // beta1 == 0: the exact solution is x0 = 0
 
-  // workspace: R[3] (r1, r2, y rotate) and W[3] (w1, w2, w rotate)
+  // workspace: R[3] (r1, r2, y rotate), W[3] (w1, w2, w rotate) and the iterate xw.  The iterate
+  // lives in the workspace so that every kernel argument of a chunk is the same from solve to
+  // solve, which is what lets the captured chunk be replayed; it is copied to x at the end.
   if (c->mr_ws_n < n) {
     if (c->mr_ws) HIPEIG_CHECK(hipFree(c->mr_ws));
     c->mr_ws = nullptr; c->mr_ws_n = 0;
     const int64_t npad = (n + 31) & ~(int64_t)31;
-    HIPEIG_CHECK(hipMalloc((void**)&c->mr_ws, (size_t)npad * 6 * sizeof(double)));
+    HIPEIG_CHECK(hipMalloc((void**)&c->mr_ws, (size_t)npad * 7 * sizeof(double)));
     c->mr_ws_n = n;
   }
   const int64_t npad = (c->mr_ws_n + 31) & ~(int64_t)31;
   double* R[3] = {c->mr_ws, c->mr_ws + npad, c->mr_ws + 2 * npad};
   double* W[3] = {c->mr_ws + 3 * npad, c->mr_ws + 4 * npad, c->mr_ws + 5 * npad};
+  double* xw = c->mr_ws + 6 * npad;
   HIPEIG_CHECK(hipMemcpyAsync(R[0], b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  HIPEIG_CHECK(hipMemsetAsync(W[0], 0, (size_t)npad * 3 * sizeof(double), c->stream));
+  HIPEIG_CHECK(hipMemsetAsync(W[0], 0, (size_t)npad * 4 * sizeof(double), c->stream));   // W[0..2] and xw
 
   MinresState* h = c->h_mr_state;
   memset(h, 0, sizeof(MinresState));
@@ -257,6 +259,8 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   h->s = 1.0 / h->beta;
   MinresState* V = c->d_mr_state;
   HIPEIG_CHECK(hipMemcpyAsync(V, h, sizeof(MinresState), hipMemcpyHostToDevice, c->stream));
+  // the pinned record is rewritten by the first chunk's copy-back; the upload above must have read it
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
 
   const int variant = hipeig_csr_pick_variant(c, A);
   if (variant < 0) return 1;
@@ -284,62 +288,116 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   a.pC = dist ? red + 1 : pC; a.nC = dist ? 1 : gE;
   a.pD = dist ? red + 2 : pD; a.nD = dist ? 1 : gE;
 
-  const int chunk = 16;
-  int k = 0;
-  while (k < maxiter) {
-    const int kend = (k + chunk < maxiter) ? k + chunk : maxiter;
-    for (; k < kend; ++k) {
-      double* r2 = R[k % 3];
-      double* yb = R[(k + 1) % 3];
-      double* r1 = R[(k + 2) % 3];
-      double* wn = W[k % 3];
-      double* w1 = W[(k + 1) % 3];
-      double* w2 = W[(k + 2) % 3];
-      const double* xg = nullptr;
-      TcooView tv = tview;
-      int ov = 0;
-      if (variant == 4) {
-        ov = hipeig_tcoow_overlap_begin(c, A, r2, &tv, &xg);      // local windows under the all-gather
-        if (ov < 0) return 4;
-      }
-      if (ov == 0 && hipeig_allgather_x(c, r2, n, A->col_stride, &xg)) return 4;
-      if (variant == 4) {
-        for (int sw = 0; sw < nsweepA; ++sw) {
-          tv.unit_begin = sw * gA;
-          hipLaunchKernelGGL((minres_ka_kernel<4>), dim3(gA), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, view, tv, xg, a, V + 0, V + 1, r2, r1, yb, pA + sw * gA);
-        }
-      } else if (variant == 3) {
-        TcooView tv = tview;
-        for (int sw = 0; sw < nsweepA; ++sw) {       // one launch per sweep; partials side by side
-          tv.unit_begin = sw * gA * 4;
-          hipLaunchKernelGGL((minres_ka_kernel<3>), dim3(gA), dim3(HIPEIG_BLOCK), hipeig_tcoo_lds_bytes(A), c->stream, view, tv, xg, a, V + 0, V + 1, r2, r1, yb, pA + sw * gA);
-        }
-      } else if (variant == 1)
-        hipLaunchKernelGGL((minres_ka_kernel<1>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream, view, tview, xg, a, V + 0, V + 1, r2, r1, yb, pA);
-      else
-        hipLaunchKernelGGL((minres_ka_kernel<2>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream, view, tview, xg, a, V + 0, V + 1, r2, r1, yb, pA);
-      if (dist) {
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pA, gA * nsweepA, red + 0);
-        if (hipeig_allreduce_sum(c, red + 0, 1)) return 4;
-      }
-      hipLaunchKernelGGL(minres_kc_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 1, V + 2, r2, yb, pC);
-      if (dist) {
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pC, gE, red + 1);
-        if (hipeig_allreduce_sum(c, red + 1, 1)) return 4;
-      }
-      hipLaunchKernelGGL(minres_kd_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 2, V + 0, r2, w1, w2, wn, x, pD);
-      if (dist) {
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pD, gE, red + 2);
-        if (hipeig_allreduce_sum(c, red + 2, 1)) return 4;
-      }
+  // One iteration's launches on the compute stream (buffer roles rotate with period 3).
+  auto enqueue_iteration = [&](int k) -> int {
+    double* r2 = R[k % 3];
+    double* yb = R[(k + 1) % 3];
+    double* r1 = R[(k + 2) % 3];
+    double* wn = W[k % 3];
+    double* w1 = W[(k + 1) % 3];
+    double* w2 = W[(k + 2) % 3];
+    const double* xg = nullptr;
+    TcooView tv = tview;
+    int ov = 0;
+    if (variant == 4) {
+      ov = hipeig_tcoow_overlap_begin(c, A, r2, &tv, &xg);      // local windows under the all-gather
+      if (ov < 0) return 4;
     }
-    HIPEIG_CHECK(hipGetLastError());
+    if (ov == 0 && hipeig_allgather_x(c, r2, n, A->col_stride, &xg)) return 4;
+    if (variant == 4) {
+      for (int sw = 0; sw < nsweepA; ++sw) {
+        tv.unit_begin = sw * gA;
+        hipLaunchKernelGGL((minres_ka_kernel<4>), dim3(gA), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, view, tv, xg, a, V + 0, V + 1, r2, r1, yb, pA + sw * gA);
+      }
+    } else if (variant == 3) {
+      for (int sw = 0; sw < nsweepA; ++sw) {       // one launch per sweep; partials side by side
+        tv.unit_begin = sw * gA * 4;
+        hipLaunchKernelGGL((minres_ka_kernel<3>), dim3(gA), dim3(HIPEIG_BLOCK), hipeig_tcoo_lds_bytes(A), c->stream, view, tv, xg, a, V + 0, V + 1, r2, r1, yb, pA + sw * gA);
+      }
+    } else if (variant == 1)
+      hipLaunchKernelGGL((minres_ka_kernel<1>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream, view, tview, xg, a, V + 0, V + 1, r2, r1, yb, pA);
+    else
+      hipLaunchKernelGGL((minres_ka_kernel<2>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream, view, tview, xg, a, V + 0, V + 1, r2, r1, yb, pA);
+    if (dist) {
+      hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pA, gA * nsweepA, red + 0);
+      if (hipeig_allreduce_sum(c, red + 0, 1)) return 4;
+    }
+    hipLaunchKernelGGL(minres_kc_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 1, V + 2, r2, yb, pC);
+    if (dist) {
+      hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pC, gE, red + 1);
+      if (hipeig_allreduce_sum(c, red + 1, 1)) return 4;
+    }
+    hipLaunchKernelGGL(minres_kd_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 2, V + 0, r2, w1, w2, wn, xw, pD);
+    if (dist) {
+      hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pD, gE, red + 2);
+      if (hipeig_allreduce_sum(c, red + 2, 1)) return 4;
+    }
+    return 0;
+  };
+  auto enqueue_check = [&]() -> int {
     hipLaunchKernelGGL(minres_check_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, a, V + 0);
     HIPEIG_CHECK(hipMemcpyAsync(h, V, sizeof(MinresState), hipMemcpyDeviceToHost, c->stream));
-    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
-    if (h->done) break;
+    return 0;
+  };
+
+  if (c->use_graph && !dist) {
+    // Single-GPU: a chunk of 18 iterations (a multiple of the rotation period, so every chunk has
+    // the same arguments) + the stop check + the copy-back is captured once as a hipGraph and
+    // replayed; iterations past maxiter are no-ops (KA's prologue raises istop = 6).  The graph is
+    // kept across solves while nothing it has baked in changes.
+    struct GraphKey {
+      const void *A, *rowptr, *col, *val, *tidx, *widx, *ws, *state;
+      int64_t n, nnz, variant, gA, nsweep, units, lds, maxiter;
+      double sigma, sign, rtol;
+    } key;
+    memset(&key, 0, sizeof(key));
+    key.A = A; key.rowptr = A->d_rowptr; key.col = A->d_col; key.val = A->d_val;
+    key.tidx = A->t_idx; key.widx = A->w_idx; key.ws = c->mr_ws; key.state = V;
+    key.n = n; key.nnz = A->nnz; key.variant = variant; key.gA = gA; key.nsweep = nsweepA;
+    key.units = (variant == 4) ? A->w_nunits : (variant == 3) ? A->t_nunits : A->n_row_blocks;
+    key.lds = (variant == 4) ? (int64_t)hipeig_tcoow_lds_bytes(A) : (variant == 3) ? (int64_t)hipeig_tcoo_lds_bytes(A) : 0;
+    key.maxiter = maxiter; key.sigma = sigma; key.sign = sign; key.rtol = rtol;
+    const int gchunk = 18;
+    if (!c->mr_graph || c->mr_graph_key_bytes != sizeof(key) || memcmp(c->mr_graph_key, &key, sizeof(key)) != 0) {
+      if (c->mr_graph) { hipGraphExecDestroy(c->mr_graph); c->mr_graph = nullptr; }
+      hipGraph_t g = nullptr;
+      HIPEIG_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      int rc = 0;
+      for (int k = 0; k < gchunk && rc == 0; ++k) rc = enqueue_iteration(k);
+      if (rc == 0) rc = enqueue_check();
+      const hipError_t ce = hipStreamEndCapture(c->stream, &g);
+      if (rc) { if (g) hipGraphDestroy(g); return rc; }
+      HIPEIG_CHECK(ce);
+      const hipError_t ie = hipGraphInstantiate(&c->mr_graph, g, nullptr, nullptr, 0);
+      hipGraphDestroy(g);
+      HIPEIG_CHECK(ie);
+      if (!c->mr_graph_key) c->mr_graph_key = malloc(sizeof(key));
+      HIPEIG_REQUIRE(c->mr_graph_key != nullptr, "out of host memory");
+      memcpy(c->mr_graph_key, &key, sizeof(key));
+      c->mr_graph_key_bytes = sizeof(key);
+    }
+    for (int k = 0; k < maxiter; k += gchunk) {
+      HIPEIG_CHECK(hipGraphLaunch(c->mr_graph, c->stream));
+      HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+      if (h->done) break;
+    }
+  } else {
+    const int chunk = 16;
+    int k = 0;
+    while (k < maxiter) {
+      const int kend = (k + chunk < maxiter) ? k + chunk : maxiter;
+      for (; k < kend; ++k) {
+        const int rc = enqueue_iteration(k);
+        if (rc) return rc;
+      }
+      HIPEIG_CHECK(hipGetLastError());
+      if (enqueue_check()) return 1;
+      HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+      if (h->done) break;
+    }
   }
   HIPEIG_REQUIRE(h->done, "MINRES left the iteration loop without a stop code");
+  HIPEIG_CHECK(hipMemcpyAsync(x, xw, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   *info = (h->istop == 6) ? maxiter : 0;
   if (out_stats) {
     out_stats[0] = h->itn; out_stats[1] = h->istop; out_stats[2] = h->rnorm; out_stats[3] = h->Anorm;

@@ -650,6 +650,10 @@ extern "C" int hipeig_csr_create(hipeig_ctx* c, int64_t nrows, int64_t ncols, in
 extern "C" int hipeig_csr_destroy(hipeig_ctx* c, hipeig_csr* A) {
   if (!A) return 0;
   hipStreamSynchronize(c->stream);
+  if (c->mr_graph && c->mr_graph_key && *(const void**)c->mr_graph_key == (const void*)A) {
+    hipGraphExecDestroy(c->mr_graph);      // the captured MINRES chunk points into this operator
+    c->mr_graph = nullptr;
+  }
   if (A->d_rowptr) hipFree(A->d_rowptr);
   if (A->d_col) hipFree(A->d_col);
   if (A->d_val) hipFree(A->d_val);
