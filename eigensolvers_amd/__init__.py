@@ -12,13 +12,14 @@ GPU; creating a ``HipContext`` / ``HipVector`` does, and fails loudly without on
 """
 from .abstract_vector import AbstractVector, LINDEP_DEFAULT_VALUE
 from .hip_vector import HipComplexVector, HipContext, HipCsrOperator, HipVector
+from .checkpoint import latest_checkpoint, load_checkpoint, save_checkpoint
 from .feast import feastDiagonalization
 from .lanczos import inexactLanczosDiagonalization, KrylovSpace, true_residual_norms
 from .subspace import (basisTransformation, find_nearest, get_pick_function_close_to_sigma,
                        get_pick_function_maxOvlp)
 
 __all__ = ["AbstractVector", "LINDEP_DEFAULT_VALUE", "HipContext", "HipCsrOperator", "HipVector", "HipComplexVector",
-           "feastDiagonalization",
+           "feastDiagonalization", "latest_checkpoint", "load_checkpoint", "save_checkpoint",
            "inexactLanczosDiagonalization", "KrylovSpace", "true_residual_norms",
            "basisTransformation", "find_nearest", "get_pick_function_close_to_sigma",
            "get_pick_function_maxOvlp"]

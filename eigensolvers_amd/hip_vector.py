@@ -271,6 +271,12 @@ class HipVector(AbstractVector):
     def _new(self, buf):
         return HipVector(buf, self.options)
 
+    @staticmethod
+    def fromArray(template, array):
+        """A vector like ``template`` (same context, shared options) from host data - the hook
+        ``checkpoint.restore_vectors`` uses."""
+        return HipVector(array, template.options, ctx=template.ctx)
+
     @property
     def array(self):
         """Host copy of the (local) data - the reference's tests read ``.array``."""

@@ -17,6 +17,11 @@ Differences from the reference HEAD, all documented in SURVEY.md's appendix:
   matrix dumps of printUtils.py;
 * a Gram-Schmidt linear dependency before the first diagonalisation returns NaN
   eigenvalues instead of raising ``UnboundLocalError`` (:357-358).
+
+Additions that are off by default: ``checkpointDir`` /
+``resumeFrom`` (the array-backend form of the per-iteration Krylov dump of :384-393, plus the
+reader the reference lacks; ``checkpoint.py``) and ``thickRestart`` (the upgrade the reference's
+comment at :415-416 asks for).  With their defaults the iteration is the reference's.
 """
 import os
 import time
@@ -26,6 +31,7 @@ from typing import List, Union
 import numpy as np
 import scipy.linalg as sla
 
+from . import checkpoint as _ckpt
 from .abstract_vector import AbstractVector
 from .subspace import (basisTransformation, eigenvalue_change, get_pick_function_close_to_sigma,
                        loewdin_transform, ritz_pairs, find_nearest)
@@ -99,6 +105,14 @@ class KrylovSpace:
         self.Y = list(vectors)
         self.S = self.cls.overlapMatrix(self.Y)
         self.Hm = None
+
+    @classmethod
+    def restored(cls, H, vectors, S, Hm):
+        """A space whose Gram matrices are already known (checkpoint resume)."""
+        self = cls.__new__(cls)
+        self.H, self.cls, self.Y = H, type(vectors[0]), list(vectors)
+        self.S, self.Hm = np.array(S), np.array(Hm)
+        return self
 
     def project(self):
         self.Hm = self.cls.matrixRepresentation(self.H, self.Y)
@@ -179,14 +193,26 @@ def inexactLanczosDiagonalization(H, v0: Union[AbstractVector, List[AbstractVect
                                   Hsolve=None, pick=None, status=None,
                                   writeOut=True, eShift=0.0, convertUnit="au",
                                   outFileName=None, summaryFileName=None,
-                                  saveTNSsEachIteration=False, saveDir="saveTNSs"):
+                                  saveTNSsEachIteration=False, saveDir="saveTNSs",
+                                  checkpointDir=None, checkpointKeep=2, resumeFrom=None,
+                                  thickRestart=0):
     """Eigenpairs of ``H`` closest to ``sigma`` by restarted (block) inexact Lanczos.
 
     Arguments and returns as in the reference (inexact_Lanczos.py:229-276): ``v0`` is one
     guess vector or a list of mutually orthonormal guesses (block size = its length); ``L``
     the Krylov dimension per restart cycle; ``maxit`` the number of cycles; ``eConv`` the
     relative eigenvalue-change tolerance.  Returns ``(ev, Y, status)`` with ``ev`` the
-    subspace eigenvalues ordered by ``pick`` and ``Y`` the matching Ritz vectors."""
+    subspace eigenvalues ordered by ``pick`` and ``Y`` the matching Ritz vectors.
+
+    Not in the reference, all off by default:
+    ``checkpointDir``  write the Krylov basis, its Gram matrices, the Ritz data and ``status`` to
+                       ``checkpointDir/krylov_{cumIter}.npz`` after every iteration, keeping the
+                       newest ``checkpointKeep`` files (0 = all);
+    ``resumeFrom``     a checkpoint file, or a directory whose newest checkpoint is taken: the run
+                       continues after that iteration and reproduces the uninterrupted run
+                       (``v0`` then only provides the backend type, options and block size);
+    ``thickRestart``   k > 0: a restart keeps k further Ritz vectors (next in ``pick`` order) in
+                       front of the nBlock picked ones instead of discarding them."""
     if convertUnit != "au":
         raise NotImplementedError("unit conversion needs the reference's in-house `util` module")
     if isinstance(v0, AbstractVector):
@@ -197,13 +223,28 @@ def inexactLanczosDiagonalization(H, v0: Union[AbstractVector, List[AbstractVect
     cls = type(v0[0])
     nBlock = len(v0)
 
-    space = KrylovSpace(H, v0)
-    if not np.allclose(space.S, np.eye(nBlock), rtol=1e-3, atol=1e-3):
-        if nBlock > 1:
-            raise RuntimeError(f"Input vectors not orthogonalized: Smat={space.S}")
-        space.Y[0].normalize()             # in place: the caller's guess is normalised (:294)
-        space.S[0, 0] = 1
-    space.project()
+    resumed = None
+    if resumeFrom is not None:
+        path = resumeFrom
+        if os.path.isdir(path):
+            rank, nranks = _ckpt._partition_of(v0[0])
+            path = _ckpt.latest_checkpoint(resumeFrom, rank, nranks)
+            if path is None:
+                raise FileNotFoundError(f"no checkpoint in {resumeFrom}")
+        resumed = _ckpt.load_checkpoint(path)
+        if resumed["status"].get("nBlock") != nBlock:
+            raise ValueError(f"checkpoint block size {resumed['status'].get('nBlock')} != {nBlock}")
+        if resumed["Y"].shape[1] != len(v0[0]):
+            raise ValueError(f"checkpoint vectors have length {resumed['Y'].shape[1]}, guess has {len(v0[0])}")
+        space = KrylovSpace.restored(H, _ckpt.restore_vectors(v0[0], resumed["Y"]), resumed["S"], resumed["Hm"])
+    else:
+        space = KrylovSpace(H, v0)
+        if not np.allclose(space.S, np.eye(nBlock), rtol=1e-3, atol=1e-3):
+            if nBlock > 1:
+                raise RuntimeError(f"Input vectors not orthogonalized: Smat={space.S}")
+            space.Y[0].normalize()             # in place: the caller's guess is normalised (:294)
+            space.S[0, 0] = 1
+        space.project()
 
     status = _new_status(status, space.Y[0], nBlock)
     if pick is None:
@@ -215,12 +256,23 @@ def inexactLanczosDiagonalization(H, v0: Union[AbstractVector, List[AbstractVect
     ev, T = None, None
     lindep_problem = False
     keep_going = True
-    for outer in range(maxit):
+    outer0, inner0 = 0, 1
+    if resumed is not None:
+        saved = resumed["status"]
+        saved["startTime"] = time.time() - float(saved.get("runTime", 0.0))    # runTime stays cumulative
+        status.update(saved)
+        ev, T = resumed["eigenvalues"], resumed["eigencoefficients"]
+        outer0, inner0 = status["outerIter"], status["innerIter"] + 1
+        keep_going = _keep_iterating(status, maxit, L)
+    for outer in range(outer0, maxit):
         status["outerIter"] = outer
-        status["KSmaxD"] = [space.Y[0].maxD]
+        if resumed is None or outer != outer0:
+            status["KSmaxD"] = [space.Y[0].maxD]
         status["fitmaxD"] = None
         nonzero = True
-        for inner in range(1, L):                       # Y0 is the first basis vector
+        first = inner0 if outer == outer0 else 1
+        thick_lindep = False
+        for inner in (range(first, L) if keep_going else ()):      # Y0 is the first basis vector
             status["innerIter"] = inner
             status["cumIter"] += 1
             # (A) nBlock shift-and-invert solves on the newest block (:319-327)
@@ -245,6 +297,15 @@ def inexactLanczosDiagonalization(H, v0: Union[AbstractVector, List[AbstractVect
                                       f"{inner} for block state {ib}, abort current Lanczos iteration and restart.")
                     break
                 status["KSmaxD"].append(space.Y[-1].maxD)
+            if lindep_problem and thickRestart and len(space) > nBlock and status["cumIter"] > 1:
+                # thick restart only: the new direction lies (to the lindep threshold) inside the kept
+                # space, i.e. that space is invariant under the resolvent.  Extract from it once more;
+                # if that is not accepted as converged, the next cycle restarts without the extras.
+                lindep_problem, thick_lindep = False, True
+                ev, T = space.ritz(pick, status)
+                _update_convergence(ev, eConv, status, writer)
+                keep_going = _keep_iterating(status, maxit, L)
+                break
             if lindep_problem:
                 ev = np.array([np.nan] * len(space))
                 break
@@ -258,6 +319,9 @@ def inexactLanczosDiagonalization(H, v0: Union[AbstractVector, List[AbstractVect
                     extra = {"status": status, "eigencoefficients": T, "eigenvalues": ev}
                     vec.ttns.saveToHDF5(f"{saveDir}/tns_{status['cumIter']}_{iv}.h5",
                                         additionalInformation=extra)
+            if checkpointDir is not None:
+                _ckpt.save_checkpoint(checkpointDir, space.Y, space.S, space.Hm, T, ev, status,
+                                      sigma=sigma, L=L, eConv=eConv, keep=checkpointKeep)
             if not keep_going:
                 break
         if lindep_problem:
@@ -273,16 +337,19 @@ def inexactLanczosDiagonalization(H, v0: Union[AbstractVector, List[AbstractVect
             space.Y = Y
             break
         # simple restart from the nBlock picked Ritz vectors (:414-436)
+        # thick restart: the next `thickRestart` Ritz vectors go in front, so that the picked
+        # block stays the newest one and the next solves are applied to it
+        extra = 0 if thick_lindep else max(0, min(int(thickRestart), len(space) - nBlock))
         guesses = []
-        for ib in range(nBlock):
-            g = basisTransformation(space.Y, T[:, ib])
+        for col in list(range(nBlock, nBlock + extra)) + list(range(nBlock)):
+            g = basisTransformation(space.Y, T[:, col])
             guesses.append(cls.normalize(g[0]))
         space = KrylovSpace(H, guesses)
         space.project()
         if not np.allclose(space.S, np.eye(len(space)), rtol=checkFitTol, atol=checkFitTol):
             warnings.warn(f"Alert:Final eigenvectors are not properly fitted. S=\n{space.S}")
             break
-        evNew = sla.eigvalsh(space.Hm, space.S)
+        evNew = sla.eigvalsh(space.Hm[extra:, extra:], space.S[extra:, extra:])
         if _restart_is_futile(evNew, eConv, status):
             break
         status["fitmaxD"] = [v.maxD for v in space.Y]

@@ -272,6 +272,28 @@ def test_lanczos_single_vector_matches_reference(hip, gapped4000):
             assert res[0] < 1e-6                 # ||H y - theta y||, eigenvalue converged to 1e-13
 
 
+def test_lanczos_checkpoint_resume_and_thick_restart_on_device(hip, gapped4000, tmp_path):
+    """Resuming from a mid-run checkpoint continues exactly where the run stood: the kernels used at
+    this size have a fixed summation order, so the resumed run is bit-identical."""
+    Hh, guess = gapped4000
+    H = hip.HipCsrOperator.from_scipy(Hh)
+    run = lambda **kw: hip.inexactLanczosDiagonalization(H, hip.HipVector(guess.copy(), _opts()), 0.02, 5, 6, 1e-12,
+                                                         writeOut=False, **kw)
+    d = str(tmp_path / "ck")
+    ev, Y, st = run(checkpointDir=d, checkpointKeep=0)
+    assert st["isConverged"] and st["cumIter"] > 5
+    for it in (2, 4, 5):
+        ev2, Y2, st2 = run(resumeFrom=f"{d}/krylov_{it:06d}.npz")
+        np.testing.assert_array_equal(ev2, ev)
+        assert st2["cumIter"] == st["cumIter"] and st2["residual"] == st["residual"]
+        assert isinstance(Y2[0], hip.HipVector)
+        np.testing.assert_array_equal(Y2[0].array, Y[0].array)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ev_t, Y_t, st_t = run(thickRestart=2)
+    assert st_t["isConverged"] and abs(ev_t[0] - ev[0]) <= 1e-10 * abs(ev[0])
+
+
 def test_lanczos_dense_reference_test_case(hip):
     """unittests/test_lanczos.py restated for HipVector (the dense matrix stored as full CSR,
     MINRES as inner solver since GCROT is not on the device yet)."""
