@@ -34,6 +34,9 @@ SIGNATURES = {
     "hipeig_comm_init": [_P, C.c_int, C.c_int, _P],
     "hipeig_comm_destroy": [_P],
     "hipeig_comm_info": [_P, _IP, _IP],
+    "hipeig_loopback_group_create": [C.c_int, C.POINTER(C.c_void_p)],
+    "hipeig_loopback_group_destroy": [_P],
+    "hipeig_comm_init_loopback": [_P, _P, C.c_int],
     "hipeig_vec_alloc": [_P, _I64, _PP],
     "hipeig_vec_free": [_P, _P],
     "hipeig_vec_upload": [_P, _P, _P, _I64],

@@ -73,6 +73,7 @@ struct hipeig_ctx {
   MinresState* h_mr_state;   // pinned
   // distributed
   void* comm;                // ncclComm_t
+  void* loop;                // in-process loopback group (rehearsal backend), or null
   int nranks, rank;
   int collectives;           // 1 when reductions / operator applications must go through RCCL
   double* x_full;            // all-gathered operand of the operator

@@ -77,3 +77,49 @@ def attach_rccl(ctx):
         uid = broadcast_bytes(uid, 128, src=0)
         ctx.attach_comm(world, rank, uid)
     return rank, world
+
+
+class LoopbackGroup:
+    """``nranks`` contexts on ONE device joined by the library's in-process loopback collectives, each
+    driven by its own host thread - a rehearsal of the row-partitioned path on a single GPU (RCCL
+    refuses two ranks on one device).  ``run(fn)`` calls ``fn(rank, ctx)`` on every rank concurrently
+    and returns the results in rank order; an exception on any rank is re-raised."""
+
+    def __init__(self, nranks, device=0):
+        import ctypes as C
+        from . import _lib
+        from .hip_vector import HipContext
+        self.nranks = int(nranks)
+        h = C.c_void_p()
+        _lib.call("hipeig_loopback_group_create", self.nranks, C.byref(h))
+        self.handle = h
+        self.contexts = [HipContext(device) for _ in range(self.nranks)]
+        for r, ctx in enumerate(self.contexts):
+            ctx.attach_loopback(self.handle, self.nranks, r)
+
+    def run(self, fn):
+        import threading
+        results, errors = [None] * self.nranks, [None] * self.nranks
+
+        def work(r):
+            try:
+                results[r] = fn(r, self.contexts[r])
+            except BaseException as exc:      # noqa: BLE001 - re-raised below
+                errors[r] = exc
+
+        threads = [threading.Thread(target=work, args=(r,), name=f"loopback-rank{r}") for r in range(self.nranks)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for e in errors:
+            if e is not None:
+                raise e
+        return results
+
+    def close(self):
+        from . import _lib
+        if self.handle is not None:
+            self.contexts = []
+            _lib.call("hipeig_loopback_group_destroy", self.handle)
+            self.handle = None

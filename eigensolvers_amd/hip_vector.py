@@ -71,6 +71,11 @@ class HipContext:
         _lib.call("hipeig_comm_init", self.handle, int(nranks), int(rank), C.cast(buf, C.c_void_p))
         self.nranks, self.rank = int(nranks), int(rank)
 
+    def attach_loopback(self, group_handle, nranks, rank):
+        """Join an in-process loopback group (``distributed.LoopbackGroup``)."""
+        _lib.call("hipeig_comm_init_loopback", self.handle, group_handle, int(rank))
+        self.nranks, self.rank = int(nranks), int(rank)
+
     # ---- memory -------------------------------------------------------------------
     def alloc(self, n):
         free = self._pool.get(n)

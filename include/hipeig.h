@@ -48,6 +48,13 @@ int hipeig_comm_unique_id(void* id128);
 int hipeig_comm_init(hipeig_ctx* ctx, int nranks, int rank, const void* id128);
 int hipeig_comm_destroy(hipeig_ctx* ctx);
 int hipeig_comm_info(hipeig_ctx* ctx, int* nranks, int* rank);
+/* Rehearsal backend: the same collectives between several contexts of ONE process (one host thread
+ * per rank; host barrier + device-to-device copies, sums in rank order).  Lets the multi-rank path
+ * be run on a single GPU, where RCCL refuses two ranks on one device.  Every rank's thread must
+ * make the same sequence of calls; a rank waiting 120 s for its peers fails instead of hanging. */
+int hipeig_loopback_group_create(int nranks, void** group_out);
+int hipeig_loopback_group_destroy(void* group);
+int hipeig_comm_init_loopback(hipeig_ctx* ctx, void* group, int rank);
 
 /* ---- vectors: replaces the ndarray held by NumpyVector (numpyVector.py:25-28) ----- */
 int hipeig_vec_alloc(hipeig_ctx* ctx, int64_t n, double** out);

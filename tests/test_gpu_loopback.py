@@ -1,0 +1,108 @@
+"""The row-partitioned multi-rank path rehearsed on ONE GPU: P contexts in this process, one host
+thread per rank, joined by the library's in-process loopback collectives (hipeig.h,
+``hipeig_comm_init_loopback``).  Everything a P-GPU run does except RCCL's own transport is
+exercised with real data from several ranks: ragged row ranges and the padded all-gather stride,
+the column remap of every kernel layout, the split (local windows / remote windows) sweep with
+rank > 0, reductions assembled from several ranks' partial sums, MINRES and the Lanczos driver
+taking identical decisions on every rank.  RCCL itself is covered on a one-rank communicator by
+test_gpu_collectives.py; real multi-GPU runs are the driver's scaling bench."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from eigensolvers_amd.distributed import LoopbackGroup, row_range
+from eigensolvers_amd.generators import guess_vector
+
+pytestmark = pytest.mark.gpu
+
+OPTS = {"linearSystemArgs": {"linearSolver": "minres", "linearIter": 2000, "linear_tol": 1e-10}}
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_partitioned_lanczos_on_loopback_ranks(hip, gapped4000, P):
+    Hh, guess = gapped4000
+    N = 4000
+    x = np.random.default_rng(3).standard_normal(N)
+    y_ref = Hh @ x
+    g = load_golden("gapped_csr_n4000_minres.npz")
+    grp = LoopbackGroup(P)
+
+    def body(rank, ctx):
+        b, e = row_range(N, P, rank)
+        H = hip.HipCsrOperator.generate(N, 32, seed=7, row_begin=b, row_end=e, ctx=ctx)
+        out = {"range": (b, e)}
+        for variant in (1, 2, 3, 4):
+            H.set_variant(variant)
+            y = hip.HipVector(x[b:e], ctx=ctx).applyOp(H).array
+            out[f"spmv{variant}"] = float(np.max(np.abs(y - y_ref[b:e])))
+        H.set_variant(0)
+        X = hip.HipVector(x[b:e], ctx=ctx)
+        out["dot"] = X.vdot(X)
+        out["norm"] = X.norm()
+        Ys = [hip.HipVector(np.random.default_rng(10 + i).standard_normal(N)[b:e], ctx=ctx) for i in range(3)]
+        out["gram"] = hip.HipVector.overlapMatrix(Ys)
+        v0 = hip.HipVector(guess[b:e].copy(), dict(OPTS), ctx=ctx)
+        ev, Y, st = hip.inexactLanczosDiagonalization(H, v0, 0.02, 8, 10, 1e-13, writeOut=False)
+        out.update(ev=ev, cumIter=st["cumIter"], conv=st["isConverged"], y0=Y[0].array,
+                   its=Y[0].last_solve_stats, res=hip.true_residual_norms(H, ev, Y, 1)[0])
+        return out
+
+    try:
+        res = grp.run(body)
+    finally:
+        grp.close()
+    full = [np.random.default_rng(10 + i).standard_normal(N) for i in range(3)]
+    G = np.array([[np.dot(a, b) for b in full] for a in full])
+    for r, o in enumerate(res):
+        assert o["range"] == row_range(N, P, r)
+        for variant in (1, 2, 3, 4):
+            assert o[f"spmv{variant}"] < 1e-12, (r, variant, o[f"spmv{variant}"])
+        assert abs(o["dot"] - np.dot(x, x)) < 1e-10 * np.dot(x, x)
+        assert abs(o["norm"] - np.linalg.norm(x)) < 1e-12 * np.linalg.norm(x)
+        np.testing.assert_allclose(o["gram"], G, rtol=0, atol=1e-10)
+        # every rank holds the same scalars, bit for bit, and took the same decisions
+        np.testing.assert_array_equal(o["ev"], res[0]["ev"])
+        assert o["dot"] == res[0]["dot"] and o["cumIter"] == res[0]["cumIter"]
+        assert abs(o["ev"][0] - g["ev"][0]) <= 1e-10 * abs(g["ev"][0])          # north-star tolerance
+        assert o["cumIter"] == int(g["cumIter"]) and o["conv"]
+        assert o["res"] < 1e-6
+    y0 = np.concatenate([o["y0"] for o in res])
+    assert y0.shape == (N,) and abs(abs(np.dot(y0, g["vec0"])) - 1) < 1e-8
+
+
+def test_split_sweep_and_minres_with_two_ranks(hip):
+    """Three column windows over two ranks: rank 0 owns window 0, rank 1 owns window 2, window 1
+    straddles both - each rank sweeps its own window under the all-gather and the rest after it."""
+    N, P = 300_000, 2
+    single = hip.HipCsrOperator.generate(N, 32, seed=5)
+    single.set_variant(2)
+    x = np.random.default_rng(4).standard_normal(N)
+    y_ref = hip.HipVector(x).applyOp(single).array
+    b_full = guess_vector(N, 2) / np.linalg.norm(guess_vector(N, 2))
+    w_ref = hip.HipVector.solve(single, hip.HipVector(b_full.copy(), dict(OPTS)), 0.02)
+    it_ref, w_ref = w_ref.last_solve_stats["iterations"], w_ref.array
+    grp = LoopbackGroup(P)
+
+    def body(rank, ctx):
+        b, e = row_range(N, P, rank)
+        H = hip.HipCsrOperator.generate(N, 32, seed=5, row_begin=b, row_end=e, ctx=ctx)
+        out = {}
+        for variant in (2, 4):
+            H.set_variant(variant)
+            y = hip.HipVector(x[b:e], ctx=ctx).applyOp(H).array
+            out[f"spmv{variant}"] = float(np.max(np.abs(y - y_ref[b:e])) / np.max(np.abs(y_ref)))
+            w = hip.HipVector.solve(H, hip.HipVector(b_full[b:e].copy(), dict(OPTS), ctx=ctx), 0.02)
+            out[f"it{variant}"] = w.last_solve_stats["iterations"]
+            out[f"w{variant}"] = w.array
+        return out
+
+    try:
+        res = grp.run(body)
+    finally:
+        grp.close()
+    for variant in (2, 4):
+        for o in res:
+            assert o[f"spmv{variant}"] < 1e-14
+            assert abs(o[f"it{variant}"] - it_ref) <= 2
+        w = np.concatenate([o[f"w{variant}"] for o in res])
+        assert np.linalg.norm(w - w_ref) <= 1e-8 * np.linalg.norm(w_ref)

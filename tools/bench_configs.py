@@ -84,14 +84,15 @@ def config2_3():
 
 
 def config5():
-    N, m0 = 20_000, 18
+    N, m0 = int(os.environ.get("FEAST_N", 20_000)), int(os.environ.get("FEAST_M0", 18))
     H = ea.HipCsrOperator.generate(N, 32, seed=7)
     Y0 = la.qr(np.random.default_rng(9).standard_normal((N, m0)), mode="economic")[0]
     opt = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 2000, "linear_tol": 1e-4, "linear_atol": 1e-12}}
     Y = [ea.HipVector(Y0[:, i].copy(), opt) for i in range(m0)]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        (ev, Yf, st), t = timed(lambda: ea.feastDiagonalization(H, Y, 8, "legendre", -0.21, 0.21, 1e-9, 4, writeOut=False))
+        (ev, Yf, st), t = timed(lambda: ea.feastDiagonalization(H, Y, 8, "legendre", -0.21, 0.21, 1e-9,
+                                                                int(os.environ.get("FEAST_MAXIT", 4)), writeOut=False))
     inside = np.sort(ev[(ev >= -0.21) & (ev <= 0.21)])
     res = ea.true_residual_norms(H, ev, Yf)
     return {"N": N, "m0": m0, "contour_points": 4, "outerIter": st["outerIter"], "residual": st["residual"],
