@@ -91,11 +91,12 @@ def config5():
     Y = [ea.HipVector(Y0[:, i].copy(), opt) for i in range(m0)]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        (ev, Yf, st), t = timed(lambda: ea.feastDiagonalization(H, Y, 8, "legendre", -0.21, 0.21, 1e-9,
-                                                                int(os.environ.get("FEAST_MAXIT", 4)), writeOut=False))
+        (ev, Yf, st), t = timed(lambda: ea.feastDiagonalization(H, Y, int(os.environ.get("FEAST_NC", 8)), "legendre", -0.21, 0.21, 1e-9,
+                                                                int(os.environ.get("FEAST_MAXIT", 4)), writeOut=True,
+                                                                summaryFileName=os.path.join(REPO, "gpurun_out", "feast_summary.out")))
     inside = np.sort(ev[(ev >= -0.21) & (ev <= 0.21)])
     res = ea.true_residual_norms(H, ev, Yf)
-    return {"N": N, "m0": m0, "contour_points": 4, "outerIter": st["outerIter"], "residual": st["residual"],
+    return {"N": N, "m0": m0, "contour_points": int(os.environ.get("FEAST_NC", 8)) // 2, "outerIter": st["outerIter"], "residual": st["residual"],
             "eigenvalues_in_window": [float(v) for v in inside], "count_in_window": int(len(inside)),
             "max_true_residual_in_window": float(max(r for e, r in zip(ev, res) if -0.21 <= e <= 0.21)),
             "seconds": round(t, 3)}
