@@ -246,6 +246,26 @@ int hipeig_allreduce_sum(hipeig_ctx* c, double* d_buf, int count) {
   return 0;
 }
 
+// Replica mode (FEAST contour points spread over GPUs): the communicator stays
+// attached but operators and vectors are whole on every rank, so reductions and products must NOT
+// go through the collectives; only hipeig_vec_allreduce does.  partitioned = 1 restores the default.
+extern "C" int hipeig_comm_set_partitioned(hipeig_ctx* c, int partitioned) {
+  HIPEIG_REQUIRE(c->comm != nullptr || c->loop != nullptr, "no communicator attached");
+  if (partitioned) comm_flags_from_env(c, c->nranks);
+  else { c->collectives = 0; c->overlap = 0; }
+  return 0;
+}
+
+// SUM over all ranks of a whole vector, in place (compute stream).
+extern "C" int hipeig_vec_allreduce(hipeig_ctx* c, double* v, int64_t n) {
+  HIPEIG_REQUIRE(c->comm != nullptr || c->loop != nullptr, "no communicator attached");
+  HIPEIG_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "bad length");
+  if (n == 0) return 0;
+  if (c->loop) return loop_allreduce_f64(c, v, (int)n, c->stream);
+  RCCL_CHECK(g_rccl.AllReduce(v, v, (size_t)n, NCCL_FLOAT64, NCCL_SUM, (ncclComm_t)c->comm, c->stream));
+  return 0;
+}
+
 // Gather the row counts of every rank (host result in ctx->row_counts) and size the
 // gathered-operand buffer: rank r's slice lives at x_full + r*stride, stride = max count.
 int hipeig_comm_setup_rows(hipeig_ctx* c, int64_t nrows_local, int64_t* stride_out) {

@@ -79,6 +79,21 @@ def attach_rccl(ctx):
     return rank, world
 
 
+class ContourReplicas:
+    """``contourComm`` of ``feastDiagonalization`` for HipVector: one contour point per GPU, whole
+    operator and vectors on every rank, one RCCL all-reduce per filtered vector (SURVEY.md section
+    8e).  Puts the context into replica mode: create the operator and the vectors AFTER this."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.rank, self.nranks = ctx.rank, ctx.nranks
+        ctx.set_partitioned(False)
+
+    def allreduce(self, vec):
+        self.ctx.allreduce_vector(vec._buf)
+        return vec
+
+
 class LoopbackGroup:
     """``nranks`` contexts on ONE device joined by the library's in-process loopback collectives, each
     driven by its own host thread - a rehearsal of the row-partitioned path on a single GPU (RCCL

@@ -8,6 +8,11 @@ the Loewdin-orthonormalised filtered space.  Backend-agnostic like the Lanczos d
 ``solve`` (with a complex shift), scalar multiplication, ``real``, ``linearCombination``,
 ``overlapMatrix`` and ``matrixRepresentation`` of ``type(Y[0])`` are used.
 
+Multi-GPU ("replicas"): with ``contourComm`` the contour points are dealt round
+robin to the ranks, every rank holding the whole operator and whole vectors; the only exchange is
+one SUM all-reduce per filtered vector after the quadrature loop (in place of the serial
+accumulation of ``updateQ``).  All ranks then carry out the same Rayleigh-Ritz step on identical data.
+
 Quadrature: only nodes with positive abscissa are kept (``positiveHalf``), so ``nc`` nodes mean
 ``nc/2`` solves per vector (util_funcs.py:146-166).  The reference's ``trapezoidal`` rule is
 restated with its quirks (off-by-one abscissae, weights (b-a)/(nc+1); util_funcs.py:14-27).
@@ -105,8 +110,12 @@ def updateQ(Q, im0, Qquad_k, k):
 
 def feastDiagonalization(A, Y, nc, quad, eMin, eMax, eConv, maxit, contourEllipseFactor=1.0,
                          writeOut=True, eShift=0.0, convertUnit="au", outFileName=None,
-                         summaryFileName=None):
-    """Arguments and returns as the reference (feast.py:126-165): ``(ev, Y, status)``."""
+                         summaryFileName=None, contourComm=None):
+    """Arguments and returns as the reference (feast.py:126-165): ``(ev, Y, status)``.
+
+    ``contourComm`` (not in the reference): an object with ``rank``, ``nranks`` and
+    ``allreduce(vector) -> vector`` (e.g. ``distributed.ContourReplicas``); contour point k is then
+    solved on rank ``k % nranks`` only."""
     if convertUnit != "au":
         raise NotImplementedError("unit conversion needs the reference's in-house `util` module")
     cls = type(Y[0])
@@ -124,11 +133,17 @@ def feastDiagonalization(A, Y, nc, quad, eMin, eMax, eConv, maxit, contourEllips
         status["outerIter"] = it
         Q = [None] * nsub
         for k in range(len(gk)):
+            if contourComm is not None and k % contourComm.nranks != contourComm.rank:
+                continue
             status["quadrature"] = k
             theta, z = contour_point(eMin, eMax, gk[k], contourEllipseFactor)
             for im0 in range(nsub):
                 term = calculateQuadrature(A, Y[im0], z, radius, theta, wk[k], contourEllipseFactor)
-                Q = updateQ(Q, im0, term, k)
+                Q = updateQ(Q, im0, term, 0 if Q[im0] is None else 1)
+        if contourComm is not None:
+            for im0 in range(nsub):
+                mine = Q[im0] if Q[im0] is not None else 0.0 * Y[im0]      # a rank without contour points
+                Q[im0] = contourComm.allreduce(mine)
         # Rayleigh-Ritz in the Loewdin-orthonormalised filtered space (feast.py:203-215)
         S = cls.overlapMatrix(Q)
         Hm = cls.matrixRepresentation(A, Q)

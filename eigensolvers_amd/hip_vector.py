@@ -76,6 +76,15 @@ class HipContext:
         _lib.call("hipeig_comm_init_loopback", self.handle, group_handle, int(rank))
         self.nranks, self.rank = int(nranks), int(rank)
 
+    def set_partitioned(self, flag):
+        """False: replica mode - whole operators and vectors on every rank, no implicit collectives;
+        only ``allreduce_vector`` exchanges data (FEAST contour replicas)."""
+        _lib.call("hipeig_comm_set_partitioned", self.handle, 1 if flag else 0)
+
+    def allreduce_vector(self, buf):
+        """SUM of a device buffer over the ranks, in place."""
+        _lib.call("hipeig_vec_allreduce", self.handle, buf.ptr, buf.n)
+
     # ---- memory -------------------------------------------------------------------
     def alloc(self, n):
         free = self._pool.get(n)

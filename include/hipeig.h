@@ -48,6 +48,13 @@ int hipeig_comm_unique_id(void* id128);
 int hipeig_comm_init(hipeig_ctx* ctx, int nranks, int rank, const void* id128);
 int hipeig_comm_destroy(hipeig_ctx* ctx);
 int hipeig_comm_info(hipeig_ctx* ctx, int* nranks, int* rank);
+/* Replica mode for work that is spread over ranks without partitioning the rows (FEAST: one contour
+ * point per GPU, feast.py:186-201): partitioned = 0 keeps the communicator but switches the implicit
+ * all-gather / all-reduce of every product / reduction off; the only exchange is then
+ * hipeig_vec_allreduce (SUM of a whole vector over the ranks, in place), which replaces the serial
+ * accumulation of the quadrature terms in updateQ (feast.py:105-121). */
+int hipeig_comm_set_partitioned(hipeig_ctx* ctx, int partitioned);
+int hipeig_vec_allreduce(hipeig_ctx* ctx, double* v, int64_t n);
 /* Rehearsal backend: the same collectives between several contexts of ONE process (one host thread
  * per rank; host barrier + device-to-device copies, sums in rank order).  Lets the multi-rank path
  * be run on a single GPU, where RCCL refuses two ranks on one device.  Every rank's thread must

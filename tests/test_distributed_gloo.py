@@ -68,3 +68,58 @@ def test_two_rank_row_partition_matches_single_process(tmp_path):
     assert int(r[0]["cumIter"]) == st["cumIter"]
     full = np.concatenate([r[0]["y0"], r[1]["y0"]])
     assert abs(abs(np.dot(full, Y[0].array)) - 1) < 1e-8
+
+
+# ---- FEAST contour replicas: contour points dealt to the ranks ---------------
+class _GlooContour:
+    """contourComm over gloo for ndarray vectors (test only)."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.rank, self.nranks = dist.get_rank(), dist.get_world_size()
+
+    def allreduce(self, vec):
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(np.ascontiguousarray(vec.array, dtype=np.float64).copy())
+        dist.all_reduce(t)
+        return type(vec)(t.numpy(), vec.options)
+
+
+def _feast_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import eigensolvers_amd as ea
+    from conftest import load_golden
+    from eigensolvers_amd import distributed as D
+    from oracle.numpy_vector import RefVector
+    dist = D.init_process_group_gloo()
+    ea.AbstractVector.register(RefVector)
+    g = load_golden("feast_n100.npz")
+    opts = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 1000, "linear_tol": 1e-2}}
+    Y = [RefVector(g["guess"][:, i].copy(), opts) for i in range(6)]
+    ev, Yf, st = ea.feastDiagonalization(g["A"], Y, 8, "legendre", 160.0, 166.0, 1e-10, 20, writeOut=False,
+                                         contourComm=_GlooContour())
+    np.savez(os.path.join(out_dir, f"feast{rank}.npz"), ev=ev, outerIter=st["outerIter"], nvec=len(Yf),
+             y0=Yf[0].array)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2])
+def test_feast_contour_replicas_match_the_serial_run(tmp_path, world):
+    """4 contour points over 2 ranks (2 + 2): every rank ends with the same eigenvalues, and they are
+    the serial run's (the reference's own run, golden file).  Uneven splits (3 and 5 ranks) run on the
+    GPU through the loopback group, tests/test_gpu_loopback.py."""
+    mp.spawn(_feast_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    from conftest import load_golden
+    g = load_golden("feast_n100.npz")
+    r = [np.load(tmp_path / f"feast{k}.npz") for k in range(world)]
+    for k in range(world):
+        np.testing.assert_array_equal(r[k]["ev"], r[0]["ev"])         # identical data after the all-reduce
+        np.testing.assert_array_equal(r[k]["y0"], r[0]["y0"])
+        np.testing.assert_allclose(r[k]["ev"], g["ev"], rtol=1e-9)
+        assert int(r[k]["outerIter"]) == int(g["outerIter"]) and int(r[k]["nvec"]) == int(g["nvec"])

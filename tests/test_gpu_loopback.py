@@ -106,3 +106,36 @@ def test_split_sweep_and_minres_with_two_ranks(hip):
             assert abs(o[f"it{variant}"] - it_ref) <= 2
         w = np.concatenate([o[f"w{variant}"] for o in res])
         assert np.linalg.norm(w - w_ref) <= 1e-8 * np.linalg.norm(w_ref)
+
+
+@pytest.mark.parametrize("P", [3, 5])
+def test_feast_contour_replicas(hip, P):
+    """FEAST with the 4 contour points dealt to P replicas (2+1+1, and 1+1+1+1+0: one rank idle), whole
+    operator on every rank, one all-reduce per filtered vector: same eigenvalues as the serial device
+    run and as the reference's own run (golden file)."""
+    import warnings
+    from eigensolvers_amd.distributed import ContourReplicas
+    g = load_golden("feast_n100.npz")
+    opts = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 1000, "linear_tol": 1e-2}}
+
+    def run(ctx, comm):
+        A = hip.HipCsrOperator.from_dense(g["A"], ctx=ctx)
+        Y = [hip.HipVector(g["guess"][:, i].copy(), dict(opts), ctx=ctx) for i in range(6)]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ev, Yf, st = hip.feastDiagonalization(A, Y, 8, "legendre", 160.0, 166.0, 1e-10, 20, writeOut=False,
+                                                  contourComm=comm)
+        return ev, st["outerIter"], len(Yf), Yf[0].array
+
+    ev_s, it_s, n_s, y_s = run(hip.HipContext.default(), None)
+    grp = LoopbackGroup(P)
+    try:
+        res = grp.run(lambda rank, ctx: run(ctx, ContourReplicas(ctx)))
+    finally:
+        grp.close()
+    for ev, it, n, y0 in res:
+        np.testing.assert_array_equal(ev, res[0][0])
+        np.testing.assert_array_equal(y0, res[0][3])
+        np.testing.assert_allclose(ev, ev_s, rtol=1e-9)
+        np.testing.assert_allclose(ev, g["ev"], rtol=1e-8)
+        assert it == it_s == int(g["outerIter"]) and n == n_s == int(g["nvec"])
