@@ -136,6 +136,11 @@ def test_feast_contour_replicas(hip, P):
     for ev, it, n, y0 in res:
         np.testing.assert_array_equal(ev, res[0][0])
         np.testing.assert_array_equal(y0, res[0][3])
-        np.testing.assert_allclose(ev, ev_s, rtol=1e-9)
-        np.testing.assert_allclose(ev, g["ev"], rtol=1e-8)
+        # the sum over contour points is grouped by rank: rounding-level changes, amplified outside the
+        # window where FEAST does not converge the values (the inner solves stop at rtol 1e-2)
+        inside = (ev_s >= 160.0) & (ev_s <= 166.0)
+        assert inside.sum() == 3
+        np.testing.assert_allclose(ev[inside], ev_s[inside], rtol=1e-9)
+        np.testing.assert_allclose(ev[inside], g["ev"][inside], rtol=1e-9)
+        np.testing.assert_allclose(ev, ev_s, rtol=1e-6)
         assert it == it_s == int(g["outerIter"]) and n == n_s == int(g["nvec"])
