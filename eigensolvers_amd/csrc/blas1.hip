@@ -6,6 +6,7 @@
 // atomics, so results are bitwise reproducible.
 #include "common.h"
 #include <math.h>
+#include <vector>
 
 struct PtrTable {
   const double* p[HIPEIG_MAX_COLS];
@@ -221,18 +222,77 @@ extern "C" int hipeig_lincomb(hipeig_ctx* c, int64_t n, int k, const double* coe
   return lincomb_impl(c, n, k, coeffs, nullptr, 1.0, vecs, out, 0);
 }
 
+// ---- block linear combination: outs[c] = sum_j C[j][c] * v_j, all k outputs in ONE pass ----
+// (basisTransformation with a coefficient matrix, util_funcs.py:229-230: the tall-skinny product
+// Y*C.)  Every thread keeps the KB output accumulators of its two rows in registers and streams the m
+// inputs past them, so the inputs are read once instead of k times: (m + k) * 8N bytes.  Pointer
+// table and coefficients are read from device memory with wave-uniform (scalar) loads.
+struct OutTable {
+  double* p[HIPEIG_MAX_COLS];
+};
+
+template <int KB>
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+lincomb_block_kernel(int64_t n, int m, int k, const double* const* __restrict__ vecs,
+                     const double* __restrict__ coef /* m x KB, row-major, zero-padded */, OutTable outs) {
+  const int64_t n2 = n >> 1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    double2 acc[KB];
+#pragma unroll
+    for (int c = 0; c < KB; ++c) acc[c] = make_double2(0.0, 0.0);
+#pragma unroll 4
+    for (int j = 0; j < m; ++j) {
+      const double2 v = reinterpret_cast<const double2*>(vecs[j])[i];
+#pragma unroll
+      for (int c = 0; c < KB; ++c) {
+        const double w = coef[j * KB + c];
+        acc[c].x = fma(w, v.x, acc[c].x);
+        acc[c].y = fma(w, v.y, acc[c].y);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < KB; ++c)
+      if (c < k) reinterpret_cast<double2*>(outs.p[c])[i] = acc[c];
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x < k) {
+    const int c = threadIdx.x;
+    double a = 0.0;
+    for (int j = 0; j < m; ++j) a = fma(coef[j * KB + c], vecs[j][n - 1], a);
+    outs.p[c][n - 1] = a;
+  }
+}
+
 extern "C" int hipeig_lincomb_block(hipeig_ctx* c, int64_t n, int m, int k, const double* C, int ldc,
                                     const double* const* vecs, double* const* outs) {
   HIPEIG_REQUIRE(m >= 1 && k >= 1 && ldc >= k, "bad shape");
-  double* col = (double*)malloc(sizeof(double) * m);
-  HIPEIG_REQUIRE(col != nullptr, "out of host memory");
-  int rc = 0;
-  for (int cidx = 0; cidx < k && !rc; ++cidx) {
-    for (int j = 0; j < m; ++j) col[j] = C[(size_t)j * ldc + cidx];
-    rc = lincomb_impl(c, n, m, col, nullptr, 1.0, vecs, outs[cidx], 0);
+  HIPEIG_REQUIRE((size_t)m <= c->ptrs_count, "too many input vectors for one call");
+  for (int j = 0; j < m; ++j)
+    for (int q = 0; q < k; ++q) HIPEIG_REQUIRE(vecs[j] != outs[q], "an output must not alias an input");
+  if (n == 0) return 0;
+  // pageable sources: the runtime has staged them when hipMemcpyAsync returns
+  HIPEIG_CHECK(hipMemcpyAsync((void*)c->d_ptrs, vecs, sizeof(double*) * m, hipMemcpyHostToDevice, c->stream));
+  const int g = grid_for(n, 2);
+  double* dcoef = c->d_partials;                      // free here: this call has no reduction
+  std::vector<double> cf((size_t)m * HIPEIG_MAX_COLS);
+  for (int c0 = 0; c0 < k; c0 += HIPEIG_MAX_COLS) {
+    const int kk = (k - c0 < HIPEIG_MAX_COLS) ? (k - c0) : HIPEIG_MAX_COLS;
+    const int KB = kk <= 4 ? 4 : kk <= 8 ? 8 : HIPEIG_MAX_COLS;
+    for (int j = 0; j < m; ++j)
+      for (int q = 0; q < KB; ++q) cf[(size_t)j * KB + q] = (q < kk) ? C[(size_t)j * ldc + c0 + q] : 0.0;
+    HIPEIG_CHECK(hipMemcpyAsync(dcoef, cf.data(), sizeof(double) * m * KB, hipMemcpyHostToDevice, c->stream));
+    OutTable ot;
+    for (int q = 0; q < HIPEIG_MAX_COLS; ++q) ot.p[q] = (q < kk) ? outs[c0 + q] : nullptr;
+    if (KB == 4)
+      hipLaunchKernelGGL((lincomb_block_kernel<4>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, m, kk, c->d_ptrs, dcoef, ot);
+    else if (KB == 8)
+      hipLaunchKernelGGL((lincomb_block_kernel<8>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, m, kk, c->d_ptrs, dcoef, ot);
+    else
+      hipLaunchKernelGGL((lincomb_block_kernel<HIPEIG_MAX_COLS>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, m, kk, c->d_ptrs, dcoef, ot);
+    HIPEIG_CHECK(hipGetLastError());
+    dcoef += (size_t)m * KB;
   }
-  free(col);
-  return rc;
+  return 0;
 }
 
 extern "C" int hipeig_multi_axpy(hipeig_ctx* c, int64_t n, int m, const double* const* Y,
@@ -324,48 +384,132 @@ extern "C" int hipeig_multi_dot(hipeig_ctx* c, int64_t n, int m, const double* c
 }
 
 // ---- Gram blocks on the matrix cores -------------------------------------------------------
-// C[i][j] = sum_r A_i[r] * B_j[r] for a 16 x 16 block of columns: v_mfma_f64_16x16x4_f64 with
-// the ROW index r as the K dimension.  Each wave streams 64-row tiles of the (up to) 32
-// columns with coalesced loads (lane = row), transposes them through LDS ([row][col], padded
-// to 17) and feeds sixteen K-steps of 4 rows to the MFMA; the 16 x 16 fp64 accumulator stays
-// in registers for the whole sweep.  Traffic: (16 + 16) * 8N bytes per block pair, against
-// 16 * 17 * 8N for sixteen multi_dot sweeps.  Per-workgroup partial blocks are summed by
+// C[i][j] = sum_r A_i[r] * B_j[r]: v_mfma_f64_16x16x4_f64 with the ROW index r as the K dimension.
+// One pass handles up to 32 columns of A and 32 of B (2 x 2 accumulator blocks of 16 x 16; the
+// symmetric case A == B reads only its 32 columns and skips the lower block).  A workgroup stages a
+// tile of 128 rows x all columns in LDS - every wave instruction is a coalesced 1 KiB read of ONE
+// column (lane = row pair, 16 bytes) - then its four waves each take a quarter of the tile's rows
+// as K-steps of 4.  LDS column stride 130 doubles (= 2 mod 32): the 32 lanes of an operand read
+// (16 columns x 2 rows) hit 32 distinct 8-byte banks.  Two workgroups per CU overlap one's loads with
+// the other's MFMAs.  Traffic: every column is read once per pass, (ma + mb) * 8N bytes against
+// 8N * ma * (mb + 1) for mb multi_dot sweeps.  Per-workgroup partial blocks are summed by
 // finalize_kernel in fixed order, like every other reduction.
 typedef double d4_t __attribute__((ext_vector_type(4)));
+#define GRAM_ROWS 128
+#define GRAM_LD 130
+#define GRAM_MAX_WG 2048
 
-template <bool SAME>
+struct PtrTable32 {
+  const double* p[32];
+};
+
+template <int NA, int NB, bool SAME>
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
-gram_mfma_kernel(int64_t n, int ma, int mb, PtrTable A, PtrTable B, double* __restrict__ partials) {
-  __shared__ double sA[4][64 * 17];
-  __shared__ double sB[SAME ? 1 : 4][SAME ? 1 : 64 * 17];
-  __shared__ double red[4][256];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  d4_t acc = {0.0, 0.0, 0.0, 0.0};
-  const int64_t ntiles = (n + 63) / 64;
-  for (int64_t t0 = (int64_t)blockIdx.x * 4; t0 < ntiles; t0 += (int64_t)gridDim.x * 4) {   // uniform trip count
-    const int64_t r = (t0 + wid) * 64 + lane;
-    const bool valid = r < n;
+gram_tile_kernel(int64_t n, int ma, int mb, PtrTable32 A, PtrTable32 B, double* __restrict__ partials) {
+  extern __shared__ double gram_lds[];
+  constexpr int CA = NA * 16, CB = SAME ? 0 : NB * 16;
+  double* tA = gram_lds;
+  double* tB = SAME ? gram_lds : gram_lds + CA * GRAM_LD;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // tell the compiler it is wave-uniform
+  d4_t acc[NA][NB];
 #pragma unroll
-    for (int cidx = 0; cidx < 16; ++cidx) {
-      sA[wid][lane * 17 + cidx] = (cidx < ma && valid) ? A.p[cidx][r] : 0.0;
-      if (!SAME) sB[wid][lane * 17 + cidx] = (cidx < mb && valid) ? B.p[cidx][r] : 0.0;
-    }
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+  const int64_t ntiles = (n + GRAM_ROWS - 1) / GRAM_ROWS;
+  // The next tile is loaded into registers while the MFMAs of the current one run out of LDS.
+  constexpr int NQ = (CA + CB) / 4;
+  double2 pre[NQ];
+  const double* srcs[NQ];                            // this wave's columns (wave-uniform: scalar registers)
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int col = wid + 4 * q;
+    srcs[q] = (col < CA) ? (col < ma ? A.p[col] : nullptr) : (col - CA < mb ? B.p[col - CA] : nullptr);
+  }
+#define GRAM_FETCH(T)                                                                                   \
+  {                                                                                                     \
+    const int64_t r = (T) * GRAM_ROWS + 2 * lane;                                                       \
+    _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                    \
+      const double* src = srcs[q];                                                                      \
+      double2 v = make_double2(0.0, 0.0);                                                               \
+      if (src && (T) < ntiles) {                                                                        \
+        if (r + 1 < n) {                                                                                \
+          typedef double gram_v2 __attribute__((ext_vector_type(2)));                                   \
+          const gram_v2 w = __builtin_nontemporal_load(reinterpret_cast<const gram_v2*>(src + r));      \
+          v = make_double2(w.x, w.y);                                                                   \
+        } else if (r < n) v.x = src[r];                                                                 \
+      }                                                                                                 \
+      pre[q] = v;                                                                                       \
+    }                                                                                                   \
+  }
+  GRAM_FETCH((int64_t)blockIdx.x)
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {           // uniform trip count per workgroup
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      *reinterpret_cast<double2*>(gram_lds + (wid + 4 * q) * GRAM_LD + 2 * lane) = pre[q];
     __syncthreads();
+    GRAM_FETCH(t + gridDim.x)
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int o = (4 * s + (lane >> 4)) * 17 + (lane & 15);
-      const double a = sA[wid][o];
-      const double b = SAME ? a : sB[wid][o];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    for (int s = 0; s < GRAM_ROWS / 16; ++s) {
+      const int row = 4 * (wid * (GRAM_ROWS / 16) + s) + (lane >> 4);
+      double a[NA], b[NB];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) a[i] = tA[(i * 16 + (lane & 15)) * GRAM_LD + row];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) b[j] = SAME ? a[j] : tB[(j * 16 + (lane & 15)) * GRAM_LD + row];
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          if (!SAME || j >= i) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
-  // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+#undef GRAM_FETCH
+  // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg.  Sum the four waves'
+  // blocks through LDS (the tile area is free now): red[wave][block][256].
+  double* red = gram_lds;
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) red[wid][((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = acc[reg];
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        red[(wid * NA * NB + i * NB + j) * 256 + ((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = acc[i][j][reg];
   __syncthreads();
-  const int e = threadIdx.x;                       // 256 threads <-> 256 block elements
-  partials[(size_t)blockIdx.x * 256 + e] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+  const int e = threadIdx.x;                       // 256 threads <-> 256 elements of a block
+#pragma unroll
+  for (int blk = 0; blk < NA * NB; ++blk) {
+    const double v = red[(0 * NA * NB + blk) * 256 + e] + red[(1 * NA * NB + blk) * 256 + e] +
+                     red[(2 * NA * NB + blk) * 256 + e] + red[(3 * NA * NB + blk) * 256 + e];
+    partials[(size_t)blockIdx.x * (NA * NB * 256) + blk * 256 + e] = v;
+  }
+}
+
+template <int NA, int NB, bool SAME>
+static int gram_tile_launch(hipeig_ctx* c, int64_t n, int na, int nb, const PtrTable32& ta, const PtrTable32& tb, int& g) {
+  constexpr size_t tile = (size_t)(NA * 16 + (SAME ? 0 : NB * 16)) * GRAM_LD * sizeof(double);
+  constexpr size_t red = (size_t)4 * NA * NB * 256 * sizeof(double);
+  constexpr size_t lds = tile > red ? tile : red;
+  static bool configured = false;
+  {
+    // workgroups per CU that fit the LDS (at most 8), capped by the partial-block workspace
+    int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    int64_t cap = (int64_t)c->num_cu * per_cu;
+    const int64_t room = (int64_t)(c->partials_doubles / ((size_t)NA * NB * 256));
+    if (cap > room) cap = room;
+    if (g > cap) g = (int)cap;
+  }
+  if (!configured) {
+    HIPEIG_CHECK(hipFuncSetAttribute((const void*)gram_tile_kernel<NA, NB, SAME>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  hipLaunchKernelGGL((gram_tile_kernel<NA, NB, SAME>), dim3(g), dim3(HIPEIG_BLOCK), lds, c->stream, n, na, nb, ta, tb, c->d_partials);
+  HIPEIG_CHECK(hipGetLastError());
+  return 0;
 }
 
 extern "C" int hipeig_gram(hipeig_ctx* c, int64_t n, int ma, const double* const* A, int mb,
@@ -383,28 +527,42 @@ extern "C" int hipeig_gram(hipeig_ctx* c, int64_t n, int ma, const double* const
     free(col);
     return rc;
   }
-  int64_t g64 = ((n + 63) / 64 + 3) / 4;
-  if (g64 > 1024) g64 = 1024;                       // 2 workgroups per CU (LDS), 256 doubles of partials each
+  bool symmetric = (ma == mb);
+  for (int i = 0; i < ma && symmetric; ++i) symmetric = (A[i] == B[i]);
+  int64_t g64 = (n + GRAM_ROWS - 1) / GRAM_ROWS;
+  if (g64 > GRAM_MAX_WG) g64 = GRAM_MAX_WG;         // upper bound; each launch lowers it to what fits a CU
   const int g = (int)g64;
-  double blk[256];
-  for (int ia = 0; ia < ma; ia += 16) {
-    for (int ib = 0; ib < mb; ib += 16) {
-      const int na = (ma - ia < 16) ? ma - ia : 16, nb = (mb - ib < 16) ? mb - ib : 16;
-      PtrTable ta, tb;
+  std::vector<double> blk(4 * 256);
+  for (int ia = 0; ia < ma; ia += 32) {
+    for (int ib = 0; ib < mb; ib += 32) {
+      if (symmetric && ib < ia) continue;           // mirrored from the upper block below
+      const int na = (ma - ia < 32) ? ma - ia : 32, nb = (mb - ib < 32) ? mb - ib : 32;
+      const int NA = (na + 15) / 16, NB = (nb + 15) / 16;
+      PtrTable32 ta, tb;
       bool same = (na == nb);
-      for (int k = 0; k < 16; ++k) {
-        ta.p[k] = (k < na) ? A[ia + k] : nullptr;
-        tb.p[k] = (k < nb) ? B[ib + k] : nullptr;
-        if (ta.p[k] != tb.p[k]) same = false;
+      for (int q = 0; q < 32; ++q) {
+        ta.p[q] = (q < na) ? A[ia + q] : nullptr;
+        tb.p[q] = (q < nb) ? B[ib + q] : nullptr;
+        if (ta.p[q] != tb.p[q]) same = false;
       }
-      if (same)
-        hipLaunchKernelGGL((gram_mfma_kernel<true>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, na, nb, ta, tb, c->d_partials);
-      else
-        hipLaunchKernelGGL((gram_mfma_kernel<false>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, na, nb, ta, tb, c->d_partials);
-      HIPEIG_CHECK(hipGetLastError());
-      if (finalize_to_host(c, g, 256, blk)) return 4;
+      int rc, gl = g;                              // the launch lowers gl to the grid it used
+      if (same && NA == 1) rc = gram_tile_launch<1, 1, true>(c, n, na, nb, ta, tb, gl);
+      else if (same) rc = gram_tile_launch<2, 2, true>(c, n, na, nb, ta, tb, gl);
+      else if (NA == 1 && NB == 1) rc = gram_tile_launch<1, 1, false>(c, n, na, nb, ta, tb, gl);
+      else if (NA == 1) rc = gram_tile_launch<1, 2, false>(c, n, na, nb, ta, tb, gl);
+      else if (NB == 1) rc = gram_tile_launch<2, 1, false>(c, n, na, nb, ta, tb, gl);
+      else rc = gram_tile_launch<2, 2, false>(c, n, na, nb, ta, tb, gl);
+      if (rc) return rc;
+      if (finalize_to_host(c, gl, NA * NB * 256, blk.data())) return 4;
       for (int i = 0; i < na; ++i)
-        for (int j = 0; j < nb; ++j) out[(size_t)(ia + i) * mb + (ib + j)] = blk[i * 16 + j];
+        for (int j = 0; j < nb; ++j) {
+          const int bi = i >> 4, bj = j >> 4;
+          double v;
+          if (same && bj < bi) v = blk[(bj * NB + bi) * 256 + (j & 15) * 16 + (i & 15)];   // lower block of a symmetric pass
+          else v = blk[(bi * NB + bj) * 256 + (i & 15) * 16 + (j & 15)];
+          out[(size_t)(ia + i) * mb + (ib + j)] = v;
+          if (symmetric && ib > ia) out[(size_t)(ib + j) * mb + (ia + i)] = v;
+        }
     }
   }
   return 0;

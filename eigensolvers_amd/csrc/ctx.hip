@@ -31,7 +31,7 @@ extern "C" int hipeig_ctx_create(int device, hipeig_ctx** out) {
   HIPEIG_CHECK(hipEventCreate(&c->ev1));
   HIPEIG_CHECK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
   HIPEIG_CHECK(hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming));
-  c->partials_doubles = (size_t)HIPEIG_MAX_PARTIALS * HIPEIG_MAX_COLS * HIPEIG_MAX_COLS;
+  c->partials_doubles = (size_t)HIPEIG_MAX_PARTIALS * HIPEIG_MAX_COLS * HIPEIG_MAX_COLS * 2;   // 8 MiB
   HIPEIG_CHECK(hipMalloc((void**)&c->d_partials, c->partials_doubles * sizeof(double)));
   c->scalars_doubles = 4096;
   HIPEIG_CHECK(hipMalloc((void**)&c->d_scalars, c->scalars_doubles * sizeof(double)));

@@ -81,6 +81,49 @@ def test_tall_skinny_against_numpy(hip, n, m):
         _within(outs[k].array, Yh @ Cm[:, k], 1e-13 * (np.abs(Yh) @ np.abs(Cm[:, k])))
 
 
+@pytest.mark.parametrize("n,ma,mb", [(777, 5, 9), (4099, 16, 16), (100001, 20, 9), (100001, 9, 20), (65536, 33, 31),
+                                     (30011, 40, 70)])
+def test_rectangular_gram_blocks(hip, n, ma, mb):
+    """hipeig_gram with two different column sets (the <y_i, H y_j> block of matrixRepresentation):
+    every accumulator-block shape of the MFMA kernel (1x1, 1x2, 2x1, 2x2, several 32-column passes)."""
+    import ctypes as C
+    from eigensolvers_amd import _lib
+    from eigensolvers_amd.hip_vector import _ptr_table
+    rng = np.random.default_rng(n + ma + 3 * mb)
+    Ah, Bh = rng.standard_normal((n, ma)), rng.standard_normal((n, mb))
+    A = [hip.HipVector(Ah[:, j].copy()) for j in range(ma)]
+    B = [hip.HipVector(Bh[:, j].copy()) for j in range(mb)]
+    ta, ka = _ptr_table([v._buf for v in A])
+    tb, kb = _ptr_table([v._buf for v in B])
+    M = np.empty((ma, mb))
+    _lib.call("hipeig_gram", A[0].ctx.handle, n, ma, ta, mb, tb, M.ctypes.data_as(C.POINTER(C.c_double)))
+    _within(M, Ah.T @ Bh, 1e-13 * (np.abs(Ah).T @ np.abs(Bh)))
+    # a shared leading part: the first min(ma, mb, 16) columns of B are A's own (partly aliased tables)
+    q = min(ma, mb, 16)
+    mixed = A[:q] + B[q:]
+    tm, km = _ptr_table([v._buf for v in mixed])
+    _lib.call("hipeig_gram", A[0].ctx.handle, n, ma, ta, mb, tm, M.ctypes.data_as(C.POINTER(C.c_double)))
+    Mh = np.concatenate([Ah[:, :q], Bh[:, q:]], axis=1)
+    _within(M, Ah.T @ Mh, 1e-13 * (np.abs(Ah).T @ np.abs(Mh)))
+
+
+@pytest.mark.parametrize("n,m,k", [(9, 2, 1), (4097, 7, 5), (100003, 33, 9), (1 << 16, 40, 17), (50001, 64, 37)])
+def test_block_combination_shapes(hip, n, m, k):
+    """hipeig_lincomb_block (Y*C, basisTransformation with a matrix): one pass for <= 16 outputs,
+    several for more; odd lengths; up to 64 inputs."""
+    rng = np.random.default_rng(n + m + k)
+    Yh = rng.standard_normal((n, m))
+    Cm = rng.standard_normal((m, k))
+    V = [hip.HipVector(Yh[:, j].copy()) for j in range(m)]
+    outs = hip.HipVector.linearCombinationBlock(V, Cm)
+    ref = Yh @ Cm
+    bound = 1e-14 * (np.abs(Yh) @ np.abs(Cm))
+    for c in range(k):
+        _within(outs[c].array, ref[:, c], bound[:, c] + 1e-300)
+    for j in range(m):                                  # inputs untouched
+        assert np.array_equal(V[j].array, Yh[:, j])
+
+
 def test_vector_ops_match_reference_golden(hip, gapped4000):
     Hh, _ = gapped4000
     N = 4000
