@@ -103,6 +103,7 @@ struct hipeig_csr {
   double* w_val;
   uint32_t* w_off;
   int32_t w_nunits, w_nwin, w_wbits, w_rw, w_wgs_per_sweep;
+  int32_t w_csplit;          // workgroups sharing one row block (column splits), 1 = none
   int64_t gather_len;        // length of the gathered operand (ncols, or stride*nranks)
   int variant;               // 0 = auto, 1 = CSR-vector, 2 = CSR-stream, 3 = TCOO (wave units), 4 = TCOO-W
   int last_variant;          // variant used by the most recent launch (0 = none yet)

@@ -19,7 +19,9 @@ CsrView hipeig_csr_view(const hipeig_csr* A);
 TcooView hipeig_tcoo_view(const hipeig_csr* A);
 TcooView hipeig_tcoow_view(const hipeig_csr* A);
 size_t hipeig_tcoow_lds_bytes(const hipeig_csr* A);
-int hipeig_tcoow_overlap_begin(hipeig_ctx* c, hipeig_csr* A, const double* x_local, TcooView* tv2, const double** xg);
+int hipeig_tcoow_prepare(hipeig_ctx* c, hipeig_csr* A, const double* x_local, TcooView* tv, const double** xg, int* ncombine);
+int64_t hipeig_tcoow_part_stride(const hipeig_csr* A);
+int hipeig_tcoow_reserve(hipeig_ctx* c, const hipeig_csr* A);
 int hipeig_spmv_grid(const hipeig_csr* A, int variant);
 int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A);
 size_t hipeig_tcoo_lds_bytes(const hipeig_csr* A);
@@ -78,6 +80,8 @@ struct MinresRowEpilogue {
   }
 };
 
+// VARIANT 1-4: the operator sweep of that layout.  VARIANT 5: the combine step of a split TCOO-W sweep
+// (T.raw_out holds T.part_base slabs of raw sums, see spmv_device.h) - same prologue, same epilogue.
 template <int VARIANT>
 __global__ void __launch_bounds__(VARIANT == 4 ? TCOOW_THREADS : HIPEIG_BLOCK)
 minres_ka_kernel(CsrView A, TcooView T, const double* __restrict__ xg, MinresArgs a, const MinresState* __restrict__ Sin,
@@ -97,10 +101,12 @@ minres_ka_kernel(CsrView A, TcooView T, const double* __restrict__ xg, MinresArg
   epi.c1 = epi.use_r1 ? S.beta / S.oldb : 0.0;
   epi.r2l = r2l; epi.r1 = r1; epi.y = y;
   double acc = 0.0;
-  if (VARIANT == 4) tcoo_wg_sweep(T, xg, epi, acc, tcoo_lds);
+  if (VARIANT == 5) tcoow_combine_sweep(T.raw_out, T.part_base, T.part_stride, T.nrows, epi, acc);
+  else if (VARIANT == 4) tcoo_wg_sweep(T, xg, epi, acc, tcoo_lds);
   else if (VARIANT == 3) tcoo_sweep(T, xg, epi, acc, tcoo_lds);
   else if (VARIANT == 2) csr_stream_sweep(A, xg, epi, acc, prod);
   else csr_vector_sweep(A, xg, epi, acc);
+  if (VARIANT == 4 && T.raw_out) return;                   // raw slabs only: the combine launch owns the partials
   acc = block_reduce_sum(acc, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = acc;      // the host offsets `partials` per sweep
 }
@@ -264,6 +270,7 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
 
   const int variant = hipeig_csr_pick_variant(c, A);
   if (variant < 0) return 1;
+  if (variant == 4 && hipeig_tcoow_reserve(c, A)) return 1;
   const CsrView view = hipeig_csr_view(A);
   const TcooView tview = (variant == 4) ? hipeig_tcoow_view(A) : hipeig_tcoo_view(A);
   if (variant == 4)
@@ -281,10 +288,12 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   double* red = c->d_scalars + 2048;    // reduced sums for the distributed path
   MinresArgs a;
   a.sigma = sigma; a.sign = sign; a.rtol = rtol; a.maxiter = maxiter;
-  const int nsweepA = (variant == 4) ? (A->w_nunits + gA - 1) / gA
+  const bool split = (variant == 4) && A->w_csplit > 1;      // raw slabs + combine launch
+  const int nsweepA = split ? 1 : (variant == 4) ? (A->w_nunits + gA - 1) / gA
                     : (variant == 3) ? (A->t_nunits + gA * 4 - 1) / (gA * 4) : 1;
   HIPEIG_REQUIRE(nsweepA * gA <= HIPEIG_MAX_PARTIALS, "too many sweeps for the partial-sum buffer");
-  a.pA = dist ? red + 0 : pA; a.nA = dist ? 1 : gA * nsweepA;
+  const int nPA = split ? gE : gA * nsweepA;                 // partial <v,y> sums one iteration leaves in pA
+  a.pA = dist ? red + 0 : pA; a.nA = dist ? 1 : nPA;
   a.pC = dist ? red + 1 : pC; a.nC = dist ? 1 : gE;
   a.pD = dist ? red + 2 : pD; a.nD = dist ? 1 : gE;
 
@@ -298,17 +307,20 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
     double* w2 = W[(k + 2) % 3];
     const double* xg = nullptr;
     TcooView tv = tview;
-    int ov = 0;
     if (variant == 4) {
-      ov = hipeig_tcoow_overlap_begin(c, A, r2, &tv, &xg);      // local windows under the all-gather
-      if (ov < 0) return 4;
-    }
-    if (ov == 0 && hipeig_allgather_x(c, r2, n, A->col_stride, &xg)) return 4;
-    if (variant == 4) {
+      int ncombine = 0;                                           // local windows under the all-gather
+      if (hipeig_tcoow_prepare(c, A, r2, &tv, &xg, &ncombine)) return 4;
       for (int sw = 0; sw < nsweepA; ++sw) {
         tv.unit_begin = sw * gA;
         hipLaunchKernelGGL((minres_ka_kernel<4>), dim3(gA), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, view, tv, xg, a, V + 0, V + 1, r2, r1, yb, pA + sw * gA);
       }
+      if (ncombine) {
+        TcooView tc = tv;
+        tc.part_base = ncombine;                                  // number of slabs to add
+        hipLaunchKernelGGL((minres_ka_kernel<5>), dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, view, tc, xg, a, V + 0, V + 1, r2, r1, yb, pA);
+      }
+    } else if (hipeig_allgather_x(c, r2, n, A->col_stride, &xg)) {
+      return 4;
     } else if (variant == 3) {
       for (int sw = 0; sw < nsweepA; ++sw) {       // one launch per sweep; partials side by side
         tv.unit_begin = sw * gA * 4;
@@ -319,7 +331,7 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
     else
       hipLaunchKernelGGL((minres_ka_kernel<2>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream, view, tview, xg, a, V + 0, V + 1, r2, r1, yb, pA);
     if (dist) {
-      hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pA, gA * nsweepA, red + 0);
+      hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pA, nPA, red + 0);
       if (hipeig_allreduce_sum(c, red + 0, 1)) return 4;
     }
     hipLaunchKernelGGL(minres_kc_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 1, V + 2, r2, yb, pC);
@@ -346,16 +358,17 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
     // replayed; iterations past maxiter are no-ops (KA's prologue raises istop = 6).  The graph is
     // kept across solves while nothing it has baked in changes.
     struct GraphKey {
-      const void *A, *rowptr, *col, *val, *tidx, *widx, *ws, *state;
-      int64_t n, nnz, variant, gA, nsweep, units, lds, maxiter;
+      const void *A, *rowptr, *col, *val, *tidx, *widx, *ws, *state, *parts;
+      int64_t n, nnz, variant, gA, nsweep, units, lds, maxiter, csplit;
       double sigma, sign, rtol;
     } key;
     memset(&key, 0, sizeof(key));
     key.A = A; key.rowptr = A->d_rowptr; key.col = A->d_col; key.val = A->d_val;
-    key.tidx = A->t_idx; key.widx = A->w_idx; key.ws = c->mr_ws; key.state = V;
+    key.tidx = A->t_idx; key.widx = A->w_idx; key.ws = c->mr_ws; key.state = V; key.parts = c->ytmp;
     key.n = n; key.nnz = A->nnz; key.variant = variant; key.gA = gA; key.nsweep = nsweepA;
     key.units = (variant == 4) ? A->w_nunits : (variant == 3) ? A->t_nunits : A->n_row_blocks;
     key.lds = (variant == 4) ? (int64_t)hipeig_tcoow_lds_bytes(A) : (variant == 3) ? (int64_t)hipeig_tcoo_lds_bytes(A) : 0;
+    key.csplit = (variant == 4) ? A->w_csplit : 0;
     key.maxiter = maxiter; key.sigma = sigma; key.sign = sign; key.rtol = rtol;
     const int gchunk = 18;
     if (!c->mr_graph || c->mr_graph_key_bytes != sizeof(key) || memcmp(c->mr_graph_key, &key, sizeof(key)) != 0) {

@@ -47,6 +47,12 @@ spmv_tcoow_kernel(TcooView T, const double* __restrict__ x, AxpyEpilogue epi) {
   tcoo_wg_sweep(T, x, epi, acc, tcoo_lds);
 }
 
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+spmv_tcoow_combine_kernel(const double* __restrict__ parts, int nparts, int64_t stride, int64_t nrows, AxpyEpilogue epi) {
+  double acc = 0.0;
+  tcoow_combine_sweep(parts, nparts, stride, nrows, epi, acc);
+}
+
 TcooView hipeig_tcoow_view(const hipeig_csr* A) {
   TcooView t;
   t.idx = A->w_idx; t.val = A->w_val; t.off = A->w_off;
@@ -58,6 +64,7 @@ TcooView hipeig_tcoow_view(const hipeig_csr* A) {
   t.nrows = A->nrows;
   t.gather_len = A->gather_len;
   t.win_lo = 0; t.win_hi = A->w_nwin; t.invert = 0; t.yinit = nullptr; t.raw_out = nullptr;
+  t.csplit = 1; t.part_base = 0; t.part_stride = 0;
   return t;
 }
 
@@ -72,6 +79,7 @@ TcooView hipeig_tcoo_view(const hipeig_csr* A) {
   t.nrows = A->nrows;
   t.gather_len = A->gather_len;
   t.win_lo = 0; t.win_hi = A->t_nwin; t.invert = 0; t.yinit = nullptr; t.raw_out = nullptr;
+  t.csplit = 1; t.part_base = 0; t.part_stride = 0;
   return t;
 }
 
@@ -92,6 +100,7 @@ int hipeig_spmv_grid(const hipeig_csr* A, int variant) {
   if (variant == 4) {
     g = A->w_wgs_per_sweep;                          // one unit per workgroup, one workgroup per CU
     if (g > A->w_nunits) g = A->w_nunits;
+    if (A->w_csplit > 1) g = (int64_t)A->w_nunits * A->w_csplit;      // split mode: always a single launch
   } else if (variant == 3) {
     g = A->t_wgs_per_sweep;                          // workgroups of ONE sweep (4 units each)
     const int64_t need = (A->t_nunits + 3) / 4;
@@ -107,33 +116,54 @@ int hipeig_spmv_grid(const hipeig_csr* A, int variant) {
   return (int)g;
 }
 
+// Partial-sum slabs of the split / overlapped sweeps (context buffer, grown on demand).
+static int tcoow_ensure_parts(hipeig_ctx* c, int64_t doubles) {
+  if (c->ytmp_n >= doubles) return 0;
+  if (c->ytmp) { if (hipFree(c->ytmp) != hipSuccess) return -1; }
+  c->ytmp = nullptr; c->ytmp_n = 0;
+  if (hipMalloc((void**)&c->ytmp, (size_t)doubles * sizeof(double)) != hipSuccess) {
+    hipeig_set_error("out of device memory for the partial-sum slabs");
+    return -1;
+  }
+  c->ytmp_n = doubles;
+  return 0;
+}
+
+int64_t hipeig_tcoow_part_stride(const hipeig_csr* A) { return (A->nrows + 63) & ~(int64_t)63; }
+
+// Allocate the slabs one product of A can need, so that no allocation happens later (a hipGraph
+// capture must not allocate).
+int hipeig_tcoow_reserve(hipeig_ctx* c, const hipeig_csr* A) {
+  if (!A->w_idx) return 0;
+  const int64_t stride = hipeig_tcoow_part_stride(A);
+  const int64_t need = (A->w_csplit > 1) ? (int64_t)(c->collectives ? 2 : 1) * A->w_csplit * stride
+                                         : (c->collectives ? A->nrows : 0);
+  return need > 0 ? tcoow_ensure_parts(c, need) : 0;
+}
+
 // Multi-GPU overlap for the TCOO-W layout.  The windows that lie entirely inside this rank's own
 // column range need only x_local, so they are swept while the all-gather of the other ranks'
 // slices runs on the communication stream; the raw partial sums go to ctx->ytmp.  The caller then
-// launches the remaining windows (`tv2`: inverted window range, accumulators started from ytmp)
-// with its own epilogue.  Returns 1 when the split path was taken (tv2 / xg set), 0 when the
-// caller should use the plain all-gather + full sweep, -1 on error.
+// launches the remaining windows (`tv2`: inverted window range) - without column splits the
+// accumulators start from ytmp and the launch runs the epilogue; with column splits both launches
+// store raw slabs and the caller combines them.  Returns 1 when the split path was taken (tv2 / xg
+// set), 0 when the caller should use the plain all-gather + full sweep, -1 on error.
 int hipeig_tcoow_overlap_begin(hipeig_ctx* c, hipeig_csr* A, const double* x_local, TcooView* tv2, const double** xg) {
   if (!c->collectives || !c->overlap || !A->w_idx || A->col_stride <= 0) return 0;
   const int64_t lo = (int64_t)c->rank * A->col_stride, hi = lo + A->nrows;
   const int64_t W = (int64_t)1 << A->w_wbits;
   const int cl0 = (int)((lo + W - 1) >> A->w_wbits), cl1 = (int)(hi >> A->w_wbits);
   if (cl1 <= cl0) return 0;                             // no window is entirely local
-  if (c->ytmp_n < A->nrows) {
-    if (c->ytmp) { if (hipFree(c->ytmp) != hipSuccess) return -1; }
-    c->ytmp = nullptr; c->ytmp_n = 0;
-    if (hipMalloc((void**)&c->ytmp, (size_t)A->nrows * sizeof(double)) != hipSuccess) {
-      hipeig_set_error("out of device memory for the overlap buffer");
-      return -1;
-    }
-    c->ytmp_n = A->nrows;
-  }
+  const int cs = A->w_csplit;
+  const int64_t stride = hipeig_tcoow_part_stride(A);
+  if (tcoow_ensure_parts(c, cs > 1 ? 2 * cs * stride : A->nrows)) return -1;
   if (hipeig_allgather_x_begin(c, x_local, A->nrows, A->col_stride)) return -1;
   TcooView t = hipeig_tcoow_view(A);
   t.win_lo = cl0; t.win_hi = cl1; t.invert = 0; t.yinit = nullptr; t.raw_out = c->ytmp;
+  t.csplit = cs; t.part_base = 0; t.part_stride = stride;
   const int g = hipeig_spmv_grid(A, 4);
   AxpyEpilogue none{0.0, 0.0, nullptr, nullptr};
-  for (int ub = 0; ub < A->w_nunits; ub += g) {
+  for (int ub = 0; ub < A->w_nunits * cs; ub += g) {
     t.unit_begin = ub;
     // x_local - lo: global column j of the local range is x_local[j - lo]
     hipLaunchKernelGGL(spmv_tcoow_kernel, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t, x_local - lo, none);
@@ -141,48 +171,59 @@ int hipeig_tcoow_overlap_begin(hipeig_ctx* c, hipeig_csr* A, const double* x_loc
   if (hipGetLastError() != hipSuccess) { hipeig_set_error("local-window launch failed"); return -1; }
   if (hipeig_allgather_x_end(c, xg)) return -1;
   *tv2 = hipeig_tcoow_view(A);
-  tv2->win_lo = cl0; tv2->win_hi = cl1; tv2->invert = 1; tv2->yinit = c->ytmp; tv2->raw_out = nullptr;
+  tv2->win_lo = cl0; tv2->win_hi = cl1; tv2->invert = 1;
+  tv2->csplit = cs; tv2->part_stride = stride;
+  if (cs > 1) { tv2->yinit = nullptr; tv2->raw_out = c->ytmp; tv2->part_base = cs; }
+  else { tv2->yinit = c->ytmp; tv2->raw_out = nullptr; tv2->part_base = 0; }
   return 1;
+}
+
+// Everything before the last TCOO-W launch of one product: the operand exchange (overlapped with the
+// local windows when possible) and the view that launch must use.  *ncombine > 0 means the launches
+// leave that many raw slabs in ctx->ytmp and the caller must run a combine kernel with its epilogue.
+int hipeig_tcoow_prepare(hipeig_ctx* c, hipeig_csr* A, const double* x_local, TcooView* tv, const double** xg, int* ncombine) {
+  const int ov = hipeig_tcoow_overlap_begin(c, A, x_local, tv, xg);
+  if (ov < 0) return 4;
+  if (ov == 0) {
+    if (hipeig_allgather_x(c, x_local, A->nrows, A->col_stride, xg)) return 4;
+    *tv = hipeig_tcoow_view(A);
+    if (A->w_csplit > 1) {
+      const int64_t stride = hipeig_tcoow_part_stride(A);
+      if (tcoow_ensure_parts(c, A->w_csplit * stride)) return 4;
+      tv->csplit = A->w_csplit; tv->part_base = 0; tv->part_stride = stride; tv->raw_out = c->ytmp;
+    }
+  }
+  *ncombine = (tv->csplit > 1) ? tv->part_base + tv->csplit : 0;
+  return 0;
 }
 
 static int launch_spmv(hipeig_ctx* c, hipeig_csr* A, double a_self, double a_sum,
                        const double* x, double* y) {
   if (A->nrows == 0) return 0;
-  const double* xg = nullptr;
-  {
-    const int variant0 = hipeig_csr_pick_variant(c, A);
-    if (variant0 < 0) return 1;
-    if (variant0 == 4) {
-      TcooView t2;
-      const int ov = hipeig_tcoow_overlap_begin(c, A, x, &t2, &xg);
-      if (ov < 0) return 4;
-      if (ov == 1) {
-        AxpyEpilogue epi2{a_self, a_sum, x, y};
-        const int g = hipeig_spmv_grid(A, 4);
-        for (int ub = 0; ub < A->w_nunits; ub += g) {
-          t2.unit_begin = ub;
-          hipLaunchKernelGGL(spmv_tcoow_kernel, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t2, xg, epi2);
-        }
-        HIPEIG_CHECK(hipGetLastError());
-        return 0;
-      }
-    }
-  }
-  if (hipeig_allgather_x(c, x, A->nrows, A->col_stride, &xg)) return 4;
+  const int variant = hipeig_csr_pick_variant(c, A);
+  if (variant < 0) return 1;
   // shift term: x restricted to this operator's rows.  Partitioned run: x IS that slice; a row
   // slab applied to a full-length operand (single process): the slice starts at row_offset.
   AxpyEpilogue epi{a_self, a_sum, c->collectives ? x : x + A->row_offset, y};
-  const int variant = hipeig_csr_pick_variant(c, A);
-  if (variant < 0) return 1;
-  const CsrView v = hipeig_csr_view(A);
+  const double* xg = nullptr;
   const int g = hipeig_spmv_grid(A, variant);
   if (variant == 4) {
-    TcooView t = hipeig_tcoow_view(A);
-    for (int ub = 0; ub < A->w_nunits; ub += g) {                // one launch per sweep
+    TcooView t;
+    int ncombine = 0;
+    if (hipeig_tcoow_prepare(c, A, x, &t, &xg, &ncombine)) return 4;
+    for (int ub = 0; ub < A->w_nunits * t.csplit; ub += g) {           // one launch per sweep
       t.unit_begin = ub;
       hipLaunchKernelGGL(spmv_tcoow_kernel, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t, xg, epi);
     }
-  } else if (variant == 3) {
+    if (ncombine)
+      hipLaunchKernelGGL(spmv_tcoow_combine_kernel, dim3(grid_for(A->nrows, 2)), dim3(HIPEIG_BLOCK), 0, c->stream,
+                         c->ytmp, ncombine, t.part_stride, A->nrows, epi);
+    HIPEIG_CHECK(hipGetLastError());
+    return 0;
+  }
+  if (hipeig_allgather_x(c, x, A->nrows, A->col_stride, &xg)) return 4;
+  const CsrView v = hipeig_csr_view(A);
+  if (variant == 3) {
     TcooView t = hipeig_tcoo_view(A);
     for (int ub = 0; ub < A->t_nunits; ub += g * 4) {            // one launch per sweep
       t.unit_begin = ub;
@@ -464,6 +505,24 @@ int hipeig_csr_build_tcoow(hipeig_ctx* c, hipeig_csr* A) {
   rw = (rw + 63) / 64 * 64;
   if (rw < 64) rw = 64;
   if (rw > TCOOW_MAX_RW) rw = TCOOW_MAX_RW;
+  // Fewer full-size row blocks than half the CUs (a small operator, or the slab of a many-GPU run):
+  // keep the row blocks as tall as the LDS allows and let `csplit` workgroups share each of them by
+  // column ranges, so that the traffic of x through the L1s is (row blocks) x |x| instead of CUs x |x|.
+  int csplit = 1;
+  {
+    const int64_t rb_min = (A->nrows + TCOOW_MAX_RW - 1) / TCOOW_MAX_RW;
+    // Worth it only when x is much larger than the L2s (measured: slab of N = 1e7 on 1/8 of the rows
+    // 0.53 -> 0.34 ms, on 1/4 0.90 -> 0.62 ms; at N = 1e6, x = 8 MB, the combine launch costs more than
+    // the sweep gains: MINRES iteration 0.141 -> 0.163 ms).
+    int want = (rb_min * 2 <= c->num_cu && A->gather_len >= 4000000) ? (int)(c->num_cu / rb_min) : 1;
+    if (const char* e = getenv("HIPEIG_TCOOW_CSPLIT")) want = atoi(e);          // tuning knob (1 = off)
+    if (want > 64) want = 64;
+    if (want > 1 && rb_min * want <= HIPEIG_MAX_PARTIALS) {
+      csplit = want;
+      rw = ((A->nrows + rb_min - 1) / rb_min + 63) / 64 * 64;
+      if (rw > TCOOW_MAX_RW) rw = TCOOW_MAX_RW;
+    }
+  }
   if (const char* e = getenv("HIPEIG_TCOOW_RW")) rw = (atoi(e) + 63) / 64 * 64;   // tuning knob
   HIPEIG_REQUIRE(rw >= 64 && rw <= TCOOW_MAX_RW && rw <= ((int64_t)1 << (32 - wbits)), "HIPEIG_TCOOW_RW out of range");
   const int64_t nunits = (A->nrows + rw - 1) / rw;
@@ -511,6 +570,7 @@ int hipeig_csr_build_tcoow(hipeig_ctx* c, hipeig_csr* A) {
   HIPEIG_CHECK(hipStreamSynchronize(c->stream));
   HIPEIG_CHECK(hipFree(d_cur));
   A->w_nunits = (int)nunits; A->w_nwin = nwin; A->w_wbits = wbits; A->w_rw = (int)rw;
+  A->w_csplit = csplit;
   int per_cu = (int)(163840 / (rw * sizeof(double) + ((size_t)nwin + 2) * sizeof(uint32_t) + 256));
   if (per_cu > 2) per_cu = 2;                          // 1024-thread workgroups: at most 32 waves per CU
   if (per_cu < 1) per_cu = 1;

@@ -154,6 +154,13 @@ struct TcooView {
   int32_t win_lo, win_hi, invert;
   const double* yinit;
   double* raw_out;
+  // column splits (TCOO-W only): when an operator (slab) has fewer row blocks than the GPU has CUs,
+  // `csplit` workgroups share one row block, each taking an equal share of the block's non-zero
+  // stream (a contiguous run of column windows), so that every CU works but x is streamed through
+  // the L1s once per ROW BLOCK instead of once per CU.  Workgroup (block b, share s) stores raw sums
+  // to raw_out + (part_base + s) * part_stride; a combine kernel adds the slabs and runs the epilogue.
+  int32_t csplit, part_base;
+  int64_t part_stride;
 };
 
 __device__ __forceinline__ void lds_add_f64(double* p, double v) {
@@ -279,13 +286,27 @@ __device__ __forceinline__ double tcoow_gather(const double* p) {
 #endif
 }
 
+// Sum of the raw partial slabs of a split sweep (fixed order) followed by the row epilogue.
+template <class Epi>
+__device__ __forceinline__ void tcoow_combine_sweep(const double* __restrict__ parts, int nparts, int64_t stride,
+                                                    int64_t nrows, const Epi& epi, double& acc) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += step) {
+    double s = parts[r];
+    for (int p = 1; p < nparts; ++p) s += parts[(int64_t)p * stride + r];
+    epi.row(r, s, acc);
+  }
+}
+
 template <class Epi>
 __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* __restrict__ x, const Epi& epi,
                                               double& acc, double* yacc /* rw doubles + (nwin+1) uint32 of LDS */) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nw = blockDim.x >> 6;
   const uint32_t cmask = (1u << T.wbits) - 1u;
-  const int u = T.unit_begin + blockIdx.x;
+  const int vb = T.unit_begin + blockIdx.x;
+  const int u = (T.csplit > 1) ? vb / T.csplit : vb;
+  const int cs = (T.csplit > 1) ? vb - u * T.csplit : 0;
   if (u >= T.nunits) return;                         // uniform for the workgroup
   uint32_t* offL = reinterpret_cast<uint32_t*>(yacc + T.rw);     // this unit's window offsets
   const int64_t r0 = (int64_t)u * T.rw;
@@ -340,8 +361,14 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
   // stream ranges of this launch: all windows, the windows in [win_lo, win_hi), or those outside
   const int nparts = T.invert ? 2 : 1;
   for (int part = 0; part < nparts; ++part) {
-    const uint32_t sbeg = T.invert ? (part == 0 ? offL[0] : offL[T.win_hi]) : offL[T.win_lo];
-    const uint32_t send = T.invert ? (part == 0 ? offL[T.win_lo] : offL[T.nwin]) : offL[T.win_hi];
+    uint32_t sbeg = T.invert ? (part == 0 ? offL[0] : offL[T.win_hi]) : offL[T.win_lo];
+    uint32_t send = T.invert ? (part == 0 ? offL[T.win_lo] : offL[T.nwin]) : offL[T.win_hi];
+    if (T.csplit > 1) {                              // this workgroup's share of the range (64-element granules)
+      const uint64_t len = send - sbeg;
+      const uint32_t b0 = sbeg + (uint32_t)((len * (uint64_t)cs / (uint64_t)T.csplit) & ~(uint64_t)63);
+      const uint32_t b1 = (cs + 1 == T.csplit) ? send : sbeg + (uint32_t)((len * (uint64_t)(cs + 1) / (uint64_t)T.csplit) & ~(uint64_t)63);
+      sbeg = b0; send = b1;
+    }
     uint32_t base = sbeg + wave_off;
     if (base < send) {
       TCOO_LOAD(idA, vA, base)
@@ -365,7 +392,8 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
   asm volatile("" ::"v"(sink));
   __syncthreads();
   if (T.raw_out) {
-    for (int k = threadIdx.x; k < T.rw && r0 + k < T.nrows; k += blockDim.x) T.raw_out[r0 + k] = yacc[k];
+    double* dst = T.raw_out + (int64_t)(T.part_base + cs) * T.part_stride;
+    for (int k = threadIdx.x; k < T.rw && r0 + k < T.nrows; k += blockDim.x) dst[r0 + k] = yacc[k];
   } else {
     for (int k = threadIdx.x; k < T.rw && r0 + k < T.nrows; k += blockDim.x) epi.row(r0 + k, yacc[k], acc);
   }

@@ -70,10 +70,15 @@ def test_partitioned_lanczos_on_loopback_ranks(hip, gapped4000, P):
     assert y0.shape == (N,) and abs(abs(np.dot(y0, g["vec0"])) - 1) < 1e-8
 
 
-def test_split_sweep_and_minres_with_two_ranks(hip):
+@pytest.mark.parametrize("csplit", [None, 3])
+def test_split_sweep_and_minres_with_two_ranks(hip, csplit, monkeypatch):
     """Three column windows over two ranks: rank 0 owns window 0, rank 1 owns window 2, window 1
-    straddles both - each rank sweeps its own window under the all-gather and the rest after it."""
+    straddles both - each rank sweeps its own window under the all-gather and the rest after it.
+    csplit = 3: additionally three workgroups per row block (column splits), i.e. the local and the
+    remote launch both leave raw slabs that a combine launch adds up - the many-GPU configuration."""
     N, P = 300_000, 2
+    if csplit:
+        monkeypatch.setenv("HIPEIG_TCOOW_CSPLIT", str(csplit))
     single = hip.HipCsrOperator.generate(N, 32, seed=5)
     single.set_variant(2)
     x = np.random.default_rng(4).standard_normal(N)

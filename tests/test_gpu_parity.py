@@ -234,6 +234,38 @@ def test_spmv_ragged_empty_long_and_unsorted_rows(hip):
         hip.HipVector(x).applyOp(A)                 # a host matrix is not a device operator
 
 
+@pytest.mark.parametrize("csplit", [2, 5, 64])
+def test_column_split_sweep(hip, csplit, monkeypatch):
+    """TCOO-W with several workgroups per row block (column splits + combine launch; the mode picked for
+    slabs of very wide operators, forced here through its tuning knob): product, fused shift and the
+    MINRES iteration built on it against the CSR-stream kernel."""
+    N = 300_000
+    H = hip.HipCsrOperator.generate(N, 32, seed=5)
+    x = hip.HipVector(np.random.default_rng(4).standard_normal(N))
+    b = hip.HipVector(np.random.default_rng(5).standard_normal(N), _opts())
+    b.normalize()
+    H.set_variant(2)
+    y_ref = x.applyOp(H)
+    w_ref = hip.HipVector.solve(H, b, 0.02)
+    monkeypatch.setenv("HIPEIG_TCOOW_CSPLIT", str(csplit))
+    H2 = hip.HipCsrOperator.generate(N, 32, seed=5)          # the layout is built on first use, with the knob set
+    H2.set_variant(4)
+    y = x.applyOp(H2)
+    assert H2.last_variant() == "column-window-blocked(workgroup)"
+    d = hip.HipVector.linearCombination([y, y_ref], [1.0, -1.0])
+    assert d.norm() <= 1e-14 * y_ref.norm()
+    ctx = hip.HipContext.default()
+    ys, ys_ref = ctx.alloc(N), ctx.alloc(N)
+    H2.apply_shifted(0.02, x._buf, ys, reverse=True)
+    H.apply_shifted(0.02, x._buf, ys_ref, reverse=True)
+    d = hip.HipVector.linearCombination([hip.HipVector(ys), hip.HipVector(ys_ref)], [1.0, -1.0])
+    assert d.norm() <= 1e-14 * hip.HipVector(ys_ref).norm()
+    w = hip.HipVector.solve(H2, b, 0.02)
+    assert w.last_solve_stats["iterations"] == w_ref.last_solve_stats["iterations"]
+    d = hip.HipVector.linearCombination([w, w_ref], [1.0, -1.0])
+    assert d.norm() <= 1e-8 * w_ref.norm()
+
+
 def test_device_generator_is_bit_identical_to_host(hip):
     for N, nnz_row, seed in ((4000, 32, 7), (3001, 64, 11), (70001, 16, 3)):
         Hd = hip.HipCsrOperator.generate(N, nnz_row, seed=seed).to_scipy()
@@ -257,8 +289,11 @@ def test_minres_tracks_the_oracle(hip, gapped4000, rtol, maxiter):
     st = W.last_solve_stats
     assert st["iterations"] == itn and st["istop"] == istop
     # Two correctly rounded MINRES runs agree to the solve tolerance, not to rounding: the
-    # Lanczos recurrence amplifies last-bit differences (summation order) as it converges.
-    xtol = max(1e-9, 10 * rtol) * np.linalg.norm(xo)
+    # Lanczos recurrence amplifies last-bit differences (summation order) as it converges, most of
+    # all in the component along the eigenvector next to the shift (gap 0.0067, i.e. an error
+    # amplification of ~1e3 on the residual tolerance).  Even the CPU oracle alone moves by 2e-5 ||x||
+    # at rtol 1e-6 when SciPy has sorted the CSR indices of its operator in place or not.
+    xtol = max(1e-9, 100 * rtol) * np.linalg.norm(xo)
     _within(W.array, xo, xtol)
     assert abs(st["rnorm"] - trace[-1]["rnorm"]) <= 0.05 * trace[-1]["rnorm"]
     assert abs(st["Anorm"] - trace[-1]["Anorm"]) <= 1e-3 * trace[-1]["Anorm"]
