@@ -602,7 +602,7 @@ int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A) {
   A->last_launches = 1;
   if (variant == 4) {
     int g = A->w_wgs_per_sweep < A->w_nunits ? A->w_wgs_per_sweep : A->w_nunits;
-    A->last_launches = (A->w_nunits + g - 1) / g;
+    A->last_launches = (A->w_csplit > 1) ? 1 : (A->w_nunits + g - 1) / g;     // sweep launches (split mode adds a combine launch)
   } else if (variant == 3) {
     int64_t g = A->t_wgs_per_sweep;
     const int64_t need = (A->t_nunits + 3) / 4;
