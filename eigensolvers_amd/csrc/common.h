@@ -68,7 +68,7 @@ struct hipeig_ctx {
   hipGraphExec_t mr_graph;
   void* mr_graph_key;        // malloc'ed copy of the key the graph was captured for
   size_t mr_graph_key_bytes;
-  int use_graph;             // HIPEIG_GRAPH (default 1)
+  int use_graph;             // HIPEIG_GRAPH (default 0)
   MinresState* d_mr_state;   // ring of 3
   MinresState* h_mr_state;   // pinned
   // distributed

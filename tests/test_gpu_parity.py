@@ -306,6 +306,33 @@ def test_minres_tracks_the_oracle(hip, gapped4000, rtol, maxiter):
     assert np.linalg.norm(r) <= 1.05 * np.linalg.norm(ro) + 1e-13
 
 
+def test_minres_graph_replay_is_bit_identical(hip, gapped4000, monkeypatch):
+    """HIPEIG_GRAPH=1 (read when a context is created): the captured 18-iteration chunk replayed for
+    every chunk and every solve gives exactly the plain-launch result; changing the tolerance or the
+    operator re-captures."""
+    Hh, guess = gapped4000
+    b = guess / np.linalg.norm(guess)
+
+    def run(ctx):
+        out = []
+        H = hip.HipCsrOperator.from_scipy(Hh, ctx=ctx)
+        for rtol in (1e-6, 1e-10, 1e-6):
+            for rhs in (b, b[::-1].copy()):
+                W = hip.HipVector.solve(H, hip.HipVector(rhs.copy(), _opts(2000, rtol), ctx=ctx), 0.02)
+                out.append((W.last_solve_stats["iterations"], W.array))
+        H2 = hip.HipCsrOperator.generate(4000, 32, seed=8, ctx=ctx)
+        W = hip.HipVector.solve(H2, hip.HipVector(b.copy(), _opts(2000, 1e-8), ctx=ctx), 0.02)
+        out.append((W.last_solve_stats["iterations"], W.array))
+        return out
+
+    plain = run(hip.HipContext.default())
+    monkeypatch.setenv("HIPEIG_GRAPH", "1")
+    graph = run(hip.HipContext(0))
+    for (it_p, w_p), (it_g, w_g) in zip(plain, graph):
+        assert it_p == it_g
+        np.testing.assert_array_equal(w_p, w_g)
+
+
 def test_solve_matches_reference_golden_and_error_behaviour(hip, gapped4000):
     Hh, guess = gapped4000
     H = hip.HipCsrOperator.from_scipy(Hh)
