@@ -255,7 +255,7 @@ lincomb_block_kernel(int64_t n, int m, int k, const double* const* __restrict__ 
     for (int c = 0; c < KB; ++c)
       if (c < k) reinterpret_cast<double2*>(outs.p[c])[i] = acc[c];
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x < k) {
+  if ((n & 1) && blockIdx.x == 0 && (int)threadIdx.x < k) {
     const int c = threadIdx.x;
     double a = 0.0;
     for (int j = 0; j < m; ++j) a = fma(coef[j * KB + c], vecs[j][n - 1], a);
@@ -336,7 +336,7 @@ multi_dot_kernel(int64_t n, int m, PtrTable tab, const double* __restrict__ x,
     if (lane == 0) lds[wid * MB + j] = r;
   }
   __syncthreads();
-  if (threadIdx.x < m) {
+  if ((int)threadIdx.x < m) {
     const int j = threadIdx.x;
     partials[(size_t)blockIdx.x * pstride + j] = lds[j] + lds[MB + j] + lds[2 * MB + j] + lds[3 * MB + j];
   }

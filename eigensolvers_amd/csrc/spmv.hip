@@ -674,6 +674,20 @@ int hipeig_csr_finalize(hipeig_ctx* c, hipeig_csr* A, const int32_t* rowptr32) {
   return 0;
 }
 
+static int csr_upload(hipeig_ctx* c, hipeig_csr* A, const int32_t* rp32, const int32_t* col, const double* val) {
+  const int64_t nrows = A->nrows, nnz = A->nnz;
+  HIPEIG_CHECK(hipMalloc((void**)&A->d_rowptr, (size_t)(nrows + 1) * sizeof(int32_t)));
+  HIPEIG_CHECK(hipMalloc((void**)&A->d_col, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t)));
+  HIPEIG_CHECK(hipMalloc((void**)&A->d_val, (size_t)(nnz > 0 ? nnz : 1) * sizeof(double)));
+  HIPEIG_CHECK(hipMemcpyAsync(A->d_rowptr, rp32, (size_t)(nrows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  if (nnz > 0) {
+    HIPEIG_CHECK(hipMemcpyAsync(A->d_col, col, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPEIG_CHECK(hipMemcpyAsync(A->d_val, val, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 extern "C" int hipeig_csr_create(hipeig_ctx* c, int64_t nrows, int64_t ncols, int64_t row_offset,
                                  const int64_t* rowptr, const int32_t* col, const double* val,
                                  hipeig_csr** out) {
@@ -692,17 +706,9 @@ extern "C" int hipeig_csr_create(hipeig_ctx* c, int64_t nrows, int64_t ncols, in
   hipeig_csr* A = (hipeig_csr*)calloc(1, sizeof(hipeig_csr));
   HIPEIG_REQUIRE(A != nullptr, "out of host memory");
   A->nrows = nrows; A->ncols = ncols; A->nnz = nnz; A->row_offset = row_offset;
-  HIPEIG_CHECK(hipMalloc((void**)&A->d_rowptr, (size_t)(nrows + 1) * sizeof(int32_t)));
-  HIPEIG_CHECK(hipMalloc((void**)&A->d_col, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t)));
-  HIPEIG_CHECK(hipMalloc((void**)&A->d_val, (size_t)(nnz > 0 ? nnz : 1) * sizeof(double)));
-  HIPEIG_CHECK(hipMemcpyAsync(A->d_rowptr, rp32.data(), (size_t)(nrows + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-  if (nnz > 0) {
-    HIPEIG_CHECK(hipMemcpyAsync(A->d_col, col, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPEIG_CHECK(hipMemcpyAsync(A->d_val, val, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  }
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
-  int rc = hipeig_csr_finalize(c, A, rp32.data());
-  if (rc) { hipeig_csr_destroy(c, A); return rc; }
+  int rc = csr_upload(c, A, rp32.data(), col, val);
+  if (rc == 0) rc = hipeig_csr_finalize(c, A, rp32.data());
+  if (rc) { hipeig_csr_destroy(c, A); return rc; }        // nothing allocated so far outlives a failure
   *out = A;
   return 0;
 }
