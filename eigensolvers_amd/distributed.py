@@ -12,6 +12,11 @@ import contextlib
 import os
 import sys
 
+# Multi-process GPU work on this driver stack needs dmabuf IPC (RCCL's intra-node transport fails with
+# "hipIpcGetMemHandle: invalid argument" otherwise).  HSA reads the variable when the first HIP call
+# initialises the runtime, so it has to be in place before a HipContext exists; an explicit setting wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 
 @contextlib.contextmanager
 def stdout_to_stderr():
