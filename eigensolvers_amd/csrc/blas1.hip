@@ -27,6 +27,16 @@ __global__ void finalize_kernel(const double* __restrict__ partials, int nblocks
 }
 
 static int finalize_to_host(hipeig_ctx* c, int nblocks, int ncols, double* host_out) {
+  if (host_out && !c->collectives && c->h_scalars_dev) {
+    // single GPU: the stage-2 kernel stores straight into the pinned host buffer (mapped into the
+    // device's address space), so the result needs a stream wait but no copy command
+    hipLaunchKernelGGL(finalize_kernel, dim3(ncols), dim3(HIPEIG_BLOCK), 0, c->stream,
+                       c->d_partials, nblocks, ncols, c->h_scalars_dev);
+    HIPEIG_CHECK(hipGetLastError());
+    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(host_out, c->h_scalars, sizeof(double) * ncols);
+    return 0;
+  }
   hipLaunchKernelGGL(finalize_kernel, dim3(ncols), dim3(HIPEIG_BLOCK), 0, c->stream,
                      c->d_partials, nblocks, ncols, c->d_scalars);
   HIPEIG_CHECK(hipGetLastError());

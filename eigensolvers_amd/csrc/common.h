@@ -56,6 +56,7 @@ struct hipeig_ctx {
   size_t partials_doubles;
   double* d_scalars;         // small device scalar area (results of reductions)
   double* h_scalars;         // pinned host mirror
+  double* h_scalars_dev;     // the same buffer as the device sees it (null if it cannot be mapped)
   size_t scalars_doubles;
   const double** d_ptrs;     // device pointer tables for tall-skinny kernels
   const double** h_ptrs;     // pinned staging of the same

@@ -37,6 +37,12 @@ extern "C" int hipeig_ctx_create(int device, hipeig_ctx** out) {
   HIPEIG_CHECK(hipMalloc((void**)&c->d_scalars, c->scalars_doubles * sizeof(double)));
   HIPEIG_CHECK(hipHostMalloc((void**)&c->h_scalars, c->scalars_doubles * sizeof(double),
                              hipHostMallocDefault));
+  {
+    void* dev = nullptr;
+    const char* e = getenv("HIPEIG_MAPPED_SCALARS");            // 0: always copy results back (default 1)
+    if (!(e && atoi(e) == 0) && hipHostGetDevicePointer(&dev, c->h_scalars, 0) == hipSuccess) c->h_scalars_dev = (double*)dev;
+    else (void)hipGetLastError();
+  }
   c->ptrs_count = 1024;
   HIPEIG_CHECK(hipMalloc((void**)&c->d_ptrs, c->ptrs_count * sizeof(double*)));
   HIPEIG_CHECK(hipHostMalloc((void**)&c->h_ptrs, c->ptrs_count * sizeof(double*),
