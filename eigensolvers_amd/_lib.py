@@ -59,6 +59,8 @@ SIGNATURES = {
     "hipeig_orthonormalize": [_P, _I64, C.c_int, _PP, _P, _D, C.c_int, _DP, _IP],
     "hipeig_mgs_project": [_P, _I64, C.c_int, _PP, _P, _DP],
     "hipeig_pair_mgs_project": [_P, _I64, C.c_int, _PP, _PP, _P, _P, _DP],
+    "hipeig_arnoldi_step": [_P, _I64, C.c_int, _PP, _P, _DP],
+    "hipeig_pair_arnoldi_step": [_P, _I64, C.c_int, _PP, _PP, _P, _P, _DP],
     "hipeig_csr_create": [_P, _I64, _I64, _I64, _I64P, _I32P, _DP, _PP],
     "hipeig_csr_generate": [_P, _I64, _I64, _I64, C.c_int, C.c_uint64, _D, C.c_uint32, _DP, C.c_int, _PP],
     "hipeig_csr_destroy": [_P, _P],

@@ -729,6 +729,97 @@ extern "C" int hipeig_pair_mgs_project(hipeig_ctx* c, int64_t n, int m, const do
   return 0;
 }
 
+// ---- one Arnoldi step of a GMRES-type solver with a single host round trip ---------------------
+// scipy _fgmres per inner iteration (the loop behind the reference's gcrotmk, numpyVector.py:161):
+//   w_norm = ||w||;  for v in [C..., V...]: h = <v, w>, w -= h v;  h_last = ||w||;  w *= 1/h_last (if finite)
+// Everything stays on the device; out = [ ||w||^2 before, h_0 .. h_{m-1}, ||w||^2 after ] comes back in one
+// copy (for pairs: complex h as (re, im), so 2m + 2 doubles).  The host takes the square roots, checks the
+// breakdown condition and updates its small QR factorisation.
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+sumsq_kernel(int64_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ partials) {
+  __shared__ double lds[4];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    s = fma(a[i], a[i], s);
+    if (b) s = fma(b[i], b[i], s);
+  }
+  s = block_reduce_sum(s, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// w *= 1/sqrt(ss[0]) when that factor is finite (scipy: alpha = 1/h; if isfinite(alpha): w = scal(alpha, w))
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+scale_by_inv_norm_kernel(int64_t n, const double* __restrict__ ss, double* __restrict__ a, double* __restrict__ b) {
+  const double alpha = 1.0 / sqrt(ss[0]);
+  if (!isfinite(alpha)) return;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    a[i] *= alpha;
+    if (b) b[i] *= alpha;
+  }
+}
+
+static int arnoldi_sumsq(hipeig_ctx* c, int64_t n, const double* a, const double* b, int g, double* dst) {
+  hipLaunchKernelGGL(sumsq_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, b, c->d_partials);
+  hipLaunchKernelGGL(mgsp_reduce_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, c->d_partials, g, 1, g, dst);
+  return hipeig_allreduce_sum(c, dst, 1);
+}
+
+extern "C" int hipeig_arnoldi_step(hipeig_ctx* c, int64_t n, int m, const double* const* V, double* w, double* out) {
+  HIPEIG_REQUIRE(m >= 0 && m <= 1000 && out, "bad arguments");
+  const int g = grid_for(n, 4);
+  double* dres = c->d_scalars + 2560;                  // m + 2 doubles
+  double* red = c->d_scalars + 3600;
+  if (arnoldi_sumsq(c, n, w, nullptr, g, dres)) return 4;
+  for (int j = 0; j < m; ++j) {
+    hipLaunchKernelGGL(mgsp_dot_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, V[j], w, c->d_partials);
+    const double* p = c->d_partials;
+    int npart = g;
+    if (c->collectives) {
+      hipLaunchKernelGGL(mgsp_reduce_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, c->d_partials, g, 1, g, red);
+      if (hipeig_allreduce_sum(c, red, 1)) return 4;
+      p = red; npart = 1;
+    }
+    hipLaunchKernelGGL(mgsp_update_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, p, npart, V[j], w, dres + 1 + j);
+  }
+  if (arnoldi_sumsq(c, n, w, nullptr, g, dres + 1 + m)) return 4;
+  hipLaunchKernelGGL(scale_by_inv_norm_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, dres + 1 + m, w, (double*)nullptr);
+  HIPEIG_CHECK(hipGetLastError());
+  HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dres, sizeof(double) * (m + 2), hipMemcpyDeviceToHost, c->stream));
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  memcpy(out, c->h_scalars, sizeof(double) * (m + 2));
+  return 0;
+}
+
+extern "C" int hipeig_pair_arnoldi_step(hipeig_ctx* c, int64_t n, int m, const double* const* Vre, const double* const* Vim,
+                                        double* wre, double* wim, double* out) {
+  HIPEIG_REQUIRE(m >= 0 && m <= 500 && out, "bad arguments");
+  const int g = grid_for(n, 4);
+  double* dres = c->d_scalars + 2560;                  // 2m + 2 doubles
+  double* red = c->d_scalars + 3600;
+  if (arnoldi_sumsq(c, n, wre, wim, g, dres)) return 4;
+  for (int j = 0; j < m; ++j) {
+    hipLaunchKernelGGL(mgsp_pair_dot_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, Vre[j], Vim[j], wre, wim, c->d_partials);
+    const double* p = c->d_partials;
+    int npart = g;
+    if (c->collectives) {
+      hipLaunchKernelGGL(mgsp_reduce_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, c->d_partials, g, 2, g, red);
+      if (hipeig_allreduce_sum(c, red, 2)) return 4;
+      p = red; npart = 1;
+    }
+    hipLaunchKernelGGL(mgsp_pair_update_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, p, npart, g,
+                       Vre[j], Vim[j], wre, wim, dres + 1 + 2 * j);
+  }
+  if (arnoldi_sumsq(c, n, wre, wim, g, dres + 1 + 2 * m)) return 4;
+  hipLaunchKernelGGL(scale_by_inv_norm_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, dres + 1 + 2 * m, wre, wim);
+  HIPEIG_CHECK(hipGetLastError());
+  HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dres, sizeof(double) * (2 * m + 2), hipMemcpyDeviceToHost, c->stream));
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  memcpy(out, c->h_scalars, sizeof(double) * (2 * m + 2));
+  return 0;
+}
+
 extern "C" int hipeig_orthonormalize(hipeig_ctx* c, int64_t n, int m, const double* const* Y,
                                      double* x, double lindep, int method, double* innerprod,
                                      int* is_lindep) {

@@ -67,6 +67,16 @@ class _Ops:
                       out.ctypes.data_as(C.POINTER(C.c_double)))
         return out
 
+    def arnoldi_step(self, vs, w):
+        """||w||, sequential MGS of w against vs, ||w|| again and w /= ||w|| (when finite) in ONE call
+        and one host round trip; returns (norm before, coefficients, norm after)."""
+        m = len(vs)
+        out = np.empty(m + 2)
+        tab = (C.c_void_p * max(m, 1))(*[v.ptr for v in vs])
+        _lib.call("hipeig_arnoldi_step", self.h, self.n, m, C.cast(tab, C.POINTER(C.c_void_p)), w.ptr,
+                  out.ctypes.data_as(C.POINTER(C.c_double)))
+        return float(np.sqrt(out[0])), out[1:m + 1], float(np.sqrt(out[m + 1]))
+
     def combine(self, coeffs, vecs):
         """sum_i coeffs[i] * vecs[i] in one pass."""
         out = self.new()
@@ -148,6 +158,16 @@ class _PairOps:
                       C.cast(ti, C.POINTER(C.c_void_p)), w[0].ptr, w[1].ptr, out.ctypes.data_as(C.POINTER(C.c_double)))
         return out[0::2] + 1j * out[1::2]
 
+    def arnoldi_step(self, vs, w):
+        m = len(vs)
+        out = np.empty(2 * m + 2)
+        tr = (C.c_void_p * max(m, 1))(*[v[0].ptr for v in vs])
+        ti = (C.c_void_p * max(m, 1))(*[v[1].ptr for v in vs])
+        _lib.call("hipeig_pair_arnoldi_step", self.r.h, self.r.n, m, C.cast(tr, C.POINTER(C.c_void_p)),
+                  C.cast(ti, C.POINTER(C.c_void_p)), w[0].ptr, w[1].ptr, out.ctypes.data_as(C.POINTER(C.c_double)))
+        h = out[1:2 * m + 1]
+        return float(np.sqrt(out[0])), h[0::2] + 1j * h[1::2], float(np.sqrt(out[2 * m + 1]))
+
     def combine(self, coeffs, vecs):
         cf = np.asarray(coeffs, dtype=np.complex128)
         parts = [v[0] for v in vecs] + [v[1] for v in vecs]
@@ -170,18 +190,14 @@ def _fgmres(ops, matvec, v0, m, atol, cs):
     j = 0
     for j in range(m):
         w = matvec(vs[-1])
-        w_norm = ops.nrm2(w)
-        # (1 - C C^H) A, then modified Gram-Schmidt against V: one sequential sweep over the
-        # columns of [C, V], dot and update per column in that order, coefficients back at the end
-        coef = ops.mgs_project(list(cs) + vs, w)
+        # ||w||; (1 - C C^H) A, then modified Gram-Schmidt against V: one sequential sweep over the
+        # columns of [C, V], dot and update per column in that order; ||w|| again and w /= ||w|| when
+        # that is finite - all in one device call with the scalars copied back once
+        w_norm, coef, h_last = ops.arnoldi_step(list(cs) + vs, w)
         B[:, j] = coef[:len(cs)]
         hcur = np.zeros(j + 2, dtype=dt)
         hcur[:len(vs)] = coef[len(cs):]
-        hcur[j + 1] = ops.nrm2(w)
-        with np.errstate(over="ignore", divide="ignore"):
-            alpha = 1 / hcur[-1].real
-        if np.isfinite(alpha):
-            ops.scal(alpha, w)
+        hcur[j + 1] = h_last
         if not (hcur[-1].real > eps * w_norm):
             breakdown = True                           # w in the span of the previous vectors (or NaN)
         vs.append(w)

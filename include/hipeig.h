@@ -124,6 +124,13 @@ int hipeig_mgs_project(hipeig_ctx* ctx, int64_t n, int m, const double* const* V
                        double* coeffs);
 int hipeig_pair_mgs_project(hipeig_ctx* ctx, int64_t n, int m, const double* const* Vre,
                             const double* const* Vim, double* wre, double* wim, double* coeffs);
+/* One whole Arnoldi step of scipy's _fgmres (the inner loop of gcrotmk, numpyVector.py:161) with a single
+ * host round trip: out = [ ||w||^2 before, h_0..h_{m-1}, ||w||^2 after ]; w is orthogonalised against
+ * V_0..V_{m-1} one column after the other and then scaled by 1/||w|| when that is finite.  The pair form
+ * works on complex vectors held as (re, im) buffers: h_j = conj(V_j).w as (re, im), out has 2m + 2 doubles. */
+int hipeig_arnoldi_step(hipeig_ctx* ctx, int64_t n, int m, const double* const* V, double* w, double* out);
+int hipeig_pair_arnoldi_step(hipeig_ctx* ctx, int64_t n, int m, const double* const* Vre, const double* const* Vim,
+                             double* wre, double* wim, double* out);
 
 /* ---- sparse operator: replaces the scipy.sparse / ndarray H handed to the loop ----- */
 /* Host CSR -> device.  rowptr has nrows+1 entries (local rows), col holds GLOBAL column
