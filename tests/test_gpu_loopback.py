@@ -149,3 +149,40 @@ def test_feast_contour_replicas(hip, P):
         np.testing.assert_allclose(ev[inside], g["ev"][inside], rtol=1e-9)
         np.testing.assert_allclose(ev, ev_s, rtol=1e-6)
         assert it == it_s == int(g["outerIter"]) and n == n_s == int(g["nvec"])
+
+
+def test_eight_ranks_wide_operator(hip):
+    """Eight ranks of an operator wide enough (4.2e6 columns) that every rank's slab takes the
+    column-split path on its own (30 row blocks for 256 CUs), with the all-gather overlap, ragged
+    slabs and the padded stride - the shape of the 8-GPU benchmark run, on one GPU."""
+    N, P = 4_200_003, 8
+    single = hip.HipCsrOperator.generate(N, 16, seed=11)
+    single.set_variant(2)
+    x = np.random.default_rng(6).standard_normal(N)
+    y_ref = hip.HipVector(x).applyOp(single).array
+    opts = {"linearSystemArgs": {"linearSolver": "minres", "linearIter": 60, "linear_tol": 1e-30}}
+    b_full = guess_vector(N, 3) / np.linalg.norm(guess_vector(N, 3))
+    grp = LoopbackGroup(P)
+
+    def body(rank, ctx):
+        b, e = row_range(N, P, rank)
+        H = hip.HipCsrOperator.generate(N, 16, seed=11, row_begin=b, row_end=e, ctx=ctx)
+        y = hip.HipVector(x[b:e], ctx=ctx).applyOp(H).array
+        X = hip.HipVector(x[b:e], ctx=ctx)
+        # a fixed number of MINRES iterations (the tolerance cannot be met): exercises KA with slabs + combine
+        try:
+            hip.HipVector.solve(H, hip.HipVector(b_full[b:e].copy(), dict(opts), ctx=ctx), 0.02)
+            its = -1
+        except UserWarning:
+            its = 60
+        return float(np.max(np.abs(y - y_ref[b:e])) / np.max(np.abs(y_ref))), H.last_variant(), X.vdot(X), its
+
+    try:
+        res = grp.run(body)
+    finally:
+        grp.close()
+    for err, variant, dot, its in res:
+        assert variant == "column-window-blocked(workgroup)"
+        assert err < 1e-14
+        assert dot == res[0][2] and abs(dot - np.dot(x, x)) < 1e-10 * np.dot(x, x)
+        assert its == 60
