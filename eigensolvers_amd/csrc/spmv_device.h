@@ -249,15 +249,16 @@ __device__ __forceinline__ void tcoo_sweep(const TcooView& T, const double* __re
 }
 
 // ---- workgroup-wide units ("TCOO-W") ------------------------------------------------------
-// Same storage, but a unit is owned by a whole 512-thread workgroup (one per CU, all 160 KiB
-// of LDS as the y accumulator: up to 20224 rows) and the non-zeros of a tile are bucketed by
-// column (2 Ki-column bins) before being laid out.  The eight waves of the CU then walk the
-// same bins side by side, so lanes that need the same 128-byte line of x meet in one
-// instruction or in the 32 KiB L1: the number of L2 requests per non-zero drops from 1 to
-// about (1 - exp(-k))/k with k = (rows per CU) * (nnz per row) * 16 / ncols lines of reuse
-// (k ~ 2.1 at N = 1e7, 65 nnz/row).  The L2 request rate - not HBM - is what bounds the
-// gather (tools/gather_bench*.hip).  Adds to one row now come from several waves, so the
-// summation ORDER inside a row is not fixed run to run (values agree to rounding).
+// Same storage, but a unit (row block) is owned by a whole 1024-thread workgroup (one per CU, all
+// 160 KiB of LDS as the y accumulator: up to 20224 rows) and the non-zeros of a (row block, window)
+// tile are bucketed by 32-column bins before being laid out, so lanes that need the same 128-byte
+// line of x sit next to each other in ONE gather instruction - the only place where the 256-line
+// L1 can serve the second access (measured: a line does not survive until the wave's next gather).
+// Lines fetched per non-zero drop from 1 to about (1 - exp(-k))/k with k = (rows per block) *
+// (nnz per row) * 16 / ncols (k ~ 2.1 at N = 1e7, 65 nnz/row).  What bounds the sweep is the L1
+// pipeline's rate for this hit/miss mix, not L2 or HBM.  Adds to one row
+// come from several waves, so the summation ORDER inside a row is not fixed run to run (values
+// agree to rounding); the wave-owned TCOO variant above is the reproducible one.
 #ifndef TCOOW_THREADS
 #define TCOOW_THREADS 1024
 #endif
