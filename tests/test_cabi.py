@@ -46,3 +46,24 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.HipEigError):
         _lib.load()
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/hipeig.h compiles as C (not only C++) and a C program that references every declared
+    entry point links against libhipeig.so - the boundary carries no C++ or torch types."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    names = _header_symbols()
+    src = tmp_path / "use_all.c"
+    body = "\n".join(f"  table[{i}] = (void*)&{n};" for i, n in enumerate(names))
+    src.write_text('#include "hipeig.h"\n#include <stdio.h>\nint main(void) {\n'
+                   f"  void* table[{len(names)}];\n{body}\n"
+                   f'  printf("%d %p\\n", {len(names)}, table[0]);\n  return 0;\n}}\n')
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "use_all"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe),
+           "-L", lib_dir, "-l:libhipeig.so", f"-Wl,-rpath,{lib_dir}", "-Wl,--allow-shlib-undefined"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
