@@ -520,48 +520,37 @@ def test_state_following_by_max_overlap_on_device(hip):
 
 # ---------------------------------------------------------------- GCROT(m,k) on the device
 @pytest.mark.parametrize("n,m", [(1000, 0), (1000, 1), (100003, 5), (1 << 20, 40), (3_000_001, 7)])
-def test_arnoldi_step_cooperative_kernel_matches_multi_launch(hip, n, m, monkeypatch):
-    """hipeig_arnoldi_step / hipeig_pair_arnoldi_step: the single cooperative kernel (default on one GPU)
-    against the multi-launch path (HIPEIG_COOP=0, also what a partitioned run uses) - bit-identical
-    coefficients and vectors - and both against NumPy's sequential MGS."""
+def test_arnoldi_step_against_numpy(hip, n, m):
+    """hipeig_arnoldi_step / hipeig_pair_arnoldi_step (norm, sequential MGS, norm, scaling in one call)
+    against NumPy's evaluation of the same sequence, real and complex-as-pairs."""
     from eigensolvers_amd.gcrotmk import _Ops, _PairOps
     rng = np.random.default_rng(n + m)
     Vh = rng.standard_normal((m, n)) / np.sqrt(n)
     Vih = rng.standard_normal((m, n)) / np.sqrt(n)
     wh, wih = rng.standard_normal(n), rng.standard_normal(n)
-
-    def run(ctx):
-        ops, pops = _Ops(ctx, n), _PairOps(ctx, n)
-        V = [hip.HipVector(Vh[j].copy(), ctx=ctx)._buf for j in range(m)]
-        w = hip.HipVector(wh.copy(), ctx=ctx)
-        real = ops.arnoldi_step(V, w._buf)
-        Vp = [(hip.HipVector(Vh[j].copy(), ctx=ctx)._buf, hip.HipVector(Vih[j].copy(), ctx=ctx)._buf) for j in range(m)]
-        wr, wi = hip.HipVector(wh.copy(), ctx=ctx), hip.HipVector(wih.copy(), ctx=ctx)
-        pair = pops.arnoldi_step(Vp, (wr._buf, wi._buf))
-        return real, w.array, pair, wr.array + 1j * wi.array
-
-    coop = run(hip.HipContext.default())
-    monkeypatch.setenv("HIPEIG_COOP", "0")
-    plain = run(hip.HipContext(0))
-    for a, b in ((coop[0], plain[0]), (coop[2], plain[2])):
-        assert a[0] == b[0] and a[2] == b[2]
-        np.testing.assert_array_equal(a[1], b[1])
-    np.testing.assert_array_equal(coop[1], plain[1])
-    np.testing.assert_array_equal(coop[3], plain[3])
-    # NumPy reference of the same sequence
-    w = wh.copy(); h = []
+    ctx = hip.HipContext.default()
+    ops, pops = _Ops(ctx, n), _PairOps(ctx, n)
+    V = [hip.HipVector(Vh[j].copy())._buf for j in range(m)]
+    w = hip.HipVector(wh.copy())
+    nb_d, h_d, na_d = ops.arnoldi_step(V, w._buf)
+    wv = wh.copy(); h = []
     for j in range(m):
-        c = Vh[j] @ w; h.append(c); w -= c * Vh[j]
-    nb, na = np.linalg.norm(wh), np.linalg.norm(w)
-    assert abs(coop[0][0] - nb) <= 1e-13 * nb and abs(coop[0][2] - na) <= 1e-12 * nb
-    np.testing.assert_allclose(coop[0][1], np.array(h), rtol=0, atol=1e-12 * nb)
-    np.testing.assert_allclose(coop[1], w / na, rtol=0, atol=1e-12)
+        c = Vh[j] @ wv; h.append(c); wv -= c * Vh[j]
+    nb, na = np.linalg.norm(wh), np.linalg.norm(wv)
+    assert abs(nb_d - nb) <= 1e-13 * nb and abs(na_d - na) <= 1e-12 * nb
+    np.testing.assert_allclose(h_d, np.array(h), rtol=0, atol=1e-12 * nb)
+    np.testing.assert_allclose(w.array, wv / na, rtol=0, atol=1e-12)
+    Vp = [(hip.HipVector(Vh[j].copy())._buf, hip.HipVector(Vih[j].copy())._buf) for j in range(m)]
+    wr, wi = hip.HipVector(wh.copy()), hip.HipVector(wih.copy())
+    nb_d, h_d, na_d = pops.arnoldi_step(Vp, (wr._buf, wi._buf))
     z = wh + 1j * wih; hz = []
     for j in range(m):
         v = Vh[j] + 1j * Vih[j]
         c = np.vdot(v, z); hz.append(c); z = z - c * v
-    np.testing.assert_allclose(coop[2][1], np.array(hz, dtype=complex), rtol=0, atol=1e-12 * np.linalg.norm(wh + 1j * wih))
-    np.testing.assert_allclose(coop[3], z / np.linalg.norm(z), rtol=0, atol=1e-12)
+    nz = np.linalg.norm(wh + 1j * wih)
+    assert abs(nb_d - nz) <= 1e-13 * nz and abs(na_d - np.linalg.norm(z)) <= 1e-12 * nz
+    np.testing.assert_allclose(h_d, np.array(hz, dtype=complex), rtol=0, atol=1e-12 * nz)
+    np.testing.assert_allclose(wr.array + 1j * wi.array, z / np.linalg.norm(z), rtol=0, atol=1e-12)
 
 
 def test_gcrotmk_tracks_scipy(hip, gapped4000):
