@@ -760,6 +760,130 @@ scale_by_inv_norm_kernel(int64_t n, const double* __restrict__ ss, double* __res
   }
 }
 
+// Single-GPU form of the step: the update with column j and the dot product with column j+1 share one
+// pass (and one launch), the two norms ride on the first and the last pass: m + 2 launches and three vector
+// passes per column instead of 2m + 5 launches and five passes.  Grid, element-to-thread assignment and
+// reduction trees are those of the kernels above, so the numbers are bit-identical to the unfused path
+// (which a partitioned run keeps, because it needs an all-reduce between a dot and its update).
+// Workspace (doubles, g = grid): two phase buffers of 3g - [re | im | ||w||^2 after] - used alternately, and
+// g for ||w||^2 before at offset 6g.
+template <bool PAIR>
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+arnoldi_first_kernel(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+                     const double* __restrict__ wre, const double* __restrict__ wim, double* __restrict__ partials) {
+  __shared__ double lds[4];
+  const int g = gridDim.x;
+  const int64_t stride = (int64_t)g * blockDim.x;
+  double ss = 0.0, re = 0.0, im = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double x = wre[i], y = PAIR ? wim[i] : 0.0;
+    ss = fma(x, x, ss);
+    if (PAIR) ss = fma(y, y, ss);
+    if (a) {
+      const double p = a[i], q = PAIR ? b[i] : 0.0;
+      re = fma(p, x, re);
+      if (PAIR) { re = fma(q, y, re); im = fma(p, y, im); im = fma(-q, x, im); }
+    }
+  }
+  ss = block_reduce_sum(ss, lds);
+  re = block_reduce_sum(re, lds);
+  if (PAIR) im = block_reduce_sum(im, lds);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = re;
+    if (PAIR) partials[g + blockIdx.x] = im;
+    partials[6 * g + blockIdx.x] = ss;
+  }
+}
+
+template <bool PAIR>
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+arnoldi_column_kernel(int64_t n, const double* __restrict__ pin, double* __restrict__ pout,
+                      const double* __restrict__ a, const double* __restrict__ b,
+                      const double* __restrict__ a2, const double* __restrict__ b2, int last,
+                      double* __restrict__ wre, double* __restrict__ wim, double* __restrict__ coef_out) {
+  __shared__ double lds[4];
+  const int g = gridDim.x;
+  const double cr = block_sum_partials(pin, g, lds);
+  const double ci = PAIR ? block_sum_partials(pin + g, g, lds) : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    coef_out[0] = cr;
+    if (PAIR) coef_out[1] = ci;
+  }
+  const int64_t stride = (int64_t)g * blockDim.x;
+  double re = 0.0, im = 0.0, ss = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double x, y = 0.0;
+    if (PAIR) {
+      const double p = a[i], q = b[i];
+      x = wre[i] - (cr * p - ci * q);              // w -= c * v
+      y = wim[i] - (cr * q + ci * p);
+      wre[i] = x; wim[i] = y;
+    } else {
+      x = fma(-cr, a[i], wre[i]);
+      wre[i] = x;
+    }
+    if (last) {
+      ss = fma(x, x, ss);
+      if (PAIR) ss = fma(y, y, ss);
+    } else {
+      const double p = a2[i], q = PAIR ? b2[i] : 0.0;
+      re = fma(p, x, re);
+      if (PAIR) { re = fma(q, y, re); im = fma(p, y, im); im = fma(-q, x, im); }
+    }
+  }
+  if (last) {
+    ss = block_reduce_sum(ss, lds);
+    if (threadIdx.x == 0) pout[2 * g + blockIdx.x] = ss;
+  } else {
+    re = block_reduce_sum(re, lds);
+    if (PAIR) im = block_reduce_sum(im, lds);
+    if (threadIdx.x == 0) {
+      pout[blockIdx.x] = re;
+      if (PAIR) pout[g + blockIdx.x] = im;
+    }
+  }
+}
+
+// ||w||^2 before / after to dres, then w *= 1/||w|| when that factor is finite
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+arnoldi_last_kernel(int64_t n, const double* __restrict__ p_before, const double* __restrict__ p_after,
+                    double* __restrict__ wre, double* __restrict__ wim, double* __restrict__ d_before,
+                    double* __restrict__ d_after) {
+  __shared__ double lds[4];
+  const int g = gridDim.x;
+  const double sb = block_sum_partials(p_before, g, lds);
+  const double sa = block_sum_partials(p_after, g, lds);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *d_before = sb; *d_after = sa; }
+  const double alpha = 1.0 / sqrt(sa);
+  if (!isfinite(alpha)) return;
+  const int64_t stride = (int64_t)g * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    wre[i] *= alpha;
+    if (wim) wim[i] *= alpha;
+  }
+}
+
+template <bool PAIR>
+static int arnoldi_fused(hipeig_ctx* c, int64_t n, int m, const double* const* Vre, const double* const* Vim,
+                         double* wre, double* wim, double* dres) {
+  const int g = grid_for(n, 4);
+  const int W = PAIR ? 2 : 1;
+  double* P = c->d_partials;
+  hipLaunchKernelGGL((arnoldi_first_kernel<PAIR>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n,
+                     m > 0 ? Vre[0] : nullptr, (PAIR && m > 0) ? Vim[0] : nullptr, wre, wim, P);
+  for (int j = 0; j < m; ++j) {
+    const int last = (j + 1 == m);
+    hipLaunchKernelGGL((arnoldi_column_kernel<PAIR>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n,
+                       P + (size_t)(j & 1) * 3 * g, P + (size_t)((j + 1) & 1) * 3 * g, Vre[j], PAIR ? Vim[j] : nullptr,
+                       last ? nullptr : Vre[j + 1], (PAIR && !last) ? Vim[j + 1] : nullptr, last, wre, wim, dres + 1 + W * j);
+  }
+  const double* p_after = (m == 0) ? P + 6 * g : P + (size_t)(m & 1) * 3 * g + 2 * g;
+  hipLaunchKernelGGL(arnoldi_last_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, P + 6 * g, p_after, wre, wim,
+                     dres, dres + 1 + W * m);
+  HIPEIG_CHECK(hipGetLastError());
+  return 0;
+}
+
 static int arnoldi_sumsq(hipeig_ctx* c, int64_t n, const double* a, const double* b, int g, double* dst) {
   hipLaunchKernelGGL(sumsq_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, b, c->d_partials);
   hipLaunchKernelGGL(mgsp_reduce_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, c->d_partials, g, 1, g, dst);
@@ -771,6 +895,13 @@ extern "C" int hipeig_arnoldi_step(hipeig_ctx* c, int64_t n, int m, const double
   const int g = grid_for(n, 4);
   double* dres = c->d_scalars + 2560;                  // m + 2 doubles
   double* red = c->d_scalars + 3600;
+  if (!c->collectives) {
+    if (arnoldi_fused<false>(c, n, m, V, nullptr, w, nullptr, dres)) return 4;
+    HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dres, sizeof(double) * (m + 2), hipMemcpyDeviceToHost, c->stream));
+    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_scalars, sizeof(double) * (m + 2));
+    return 0;
+  }
   if (arnoldi_sumsq(c, n, w, nullptr, g, dres)) return 4;
   for (int j = 0; j < m; ++j) {
     hipLaunchKernelGGL(mgsp_dot_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, V[j], w, c->d_partials);
@@ -798,6 +929,13 @@ extern "C" int hipeig_pair_arnoldi_step(hipeig_ctx* c, int64_t n, int m, const d
   const int g = grid_for(n, 4);
   double* dres = c->d_scalars + 2560;                  // 2m + 2 doubles
   double* red = c->d_scalars + 3600;
+  if (!c->collectives) {
+    if (arnoldi_fused<true>(c, n, m, Vre, Vim, wre, wim, dres)) return 4;
+    HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dres, sizeof(double) * (2 * m + 2), hipMemcpyDeviceToHost, c->stream));
+    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_scalars, sizeof(double) * (2 * m + 2));
+    return 0;
+  }
   if (arnoldi_sumsq(c, n, wre, wim, g, dres)) return 4;
   for (int j = 0; j < m; ++j) {
     hipLaunchKernelGGL(mgsp_pair_dot_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, Vre[j], Vim[j], wre, wim, c->d_partials);
