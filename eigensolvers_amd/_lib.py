@@ -31,6 +31,7 @@ SIGNATURES = {
     "hipeig_ctx_sync": [_P],
     "hipeig_device_info": [_P, _I64P, C.c_char_p, C.c_int],
     "hipeig_comm_unique_id": [_P],
+    "hipeig_comm_library": [C.c_char_p, C.c_int],
     "hipeig_comm_init": [_P, C.c_int, C.c_int, _P],
     "hipeig_comm_destroy": [_P],
     "hipeig_comm_info": [_P, _IP, _IP],
@@ -71,6 +72,9 @@ SIGNATURES = {
     "hipeig_spmv_shift": [_P, _P, _D, _D, _P, _P],
     "hipeig_spmm": [_P, _P, C.c_int, _PP, _PP],
     "hipeig_minres": [_P, _P, _D, _D, _P, _P, _D, C.c_int, _IP, _DP],
+    "hipeig_minres_block": [_P, _P, _D, _D, C.c_int, _PP, _PP, _D, C.c_int, _IP, _DP],
+    "hipeig_csr_set_block_variant": [_P, C.c_int],
+    "hipeig_csr_block_info": [_P, _I64P],
     "hipeig_timer_start": [_P],
     "hipeig_timer_stop": [_P, C.POINTER(C.c_float)],
 }

@@ -1,82 +1,143 @@
 """The vector plugin surface the Lanczos loop is written against.
 
-Same names, argument meaning and return conventions as the reference's
-``AbstractVector`` (abstractVector.py:15-169): three properties, the arithmetic dunders,
-eight instance methods and the eight static hooks.  A backend is selected purely by
+Same names, parameter names, defaults and return conventions as the reference's
+``AbstractVector`` (abstractVector.py:15-169): three abstract properties, fourteen abstract
+methods and eight static hooks whose default raises.  A backend is selected purely by
 ``type(v0[0])`` (inexact_Lanczos.py:284); the operator ``H`` is an opaque token that is only
 handed back to the backend's own static hooks, so each backend defines what an operator is.
 
-The interface is written down once as a table (name -> what the loop expects of it) and the
-abstract base class is generated from it, so that the table is also what the tests and
-``INTEGRATION.md`` enumerate.
+``tests/test_surface.py`` compares every signature below - and those of ``HipVector`` - with
+``tests/golden/surface.json``, the ``inspect.signature`` dump of the reference's own classes
+(``tests/golden/make_golden_r2.py``), so a drift from the reference's interface fails a test.
 """
-from abc import ABCMeta, abstractmethod
+from abc import ABC, abstractmethod
 
 LINDEP_DEFAULT_VALUE = 1e-14          # abstractVector.py:12
 
-# name -> contract.  Properties (abstractVector.py:17-37).
-PROPERTIES = {
-    "hasExactAddition": "True when c + c* == 2 Re(c) holds exactly for this representation",
-    "dtype": "numpy dtype of the coefficients",
-    "maxD": "largest virtual bond dimension (tensor-network backends only; 0 otherwise)",
-}
-# Operators and instance methods every backend must define (abstractVector.py:39-97).
-METHODS = {
-    "__mul__": "(other) out-of-place scaling, new vector",
-    "__rmul__": "(other) scalar * vector, new vector",
-    "__truediv__": "(other) out-of-place division by a scalar, new vector",
-    "__imul__": "(other) in-place scaling (array backends raise NotImplementedError)",
-    "__itruediv__": "(other) in-place division (array backends raise NotImplementedError)",
-    "__len__": "() number of coefficients",
-    "normalize": "() normalise in place and return self",
-    "norm": "() Euclidean norm as a host float",
-    "real": "() real part, new vector",
-    "conjugate": "() complex conjugate, new vector",
-    "vdot": "(other, conjugate=True) <self|other>, conjugating self unless told otherwise; host scalar",
-    "copy": "() deep copy",
-    "applyOp": "(other) ``other @ self`` as a new vector",
-    "compress": "() compress if compressible; may return self",
-}
-# Static hooks; a backend that lacks one inherits a stub that raises (abstractVector.py:99-169).
-STATIC_HOOKS = {
-    "linearCombination": "(vectors, coeffs) sum_n coeffs[n] * vectors[n]",
-    "orthogonalize": "(xs, lindep) orthonormalise a whole set",
-    "orthogonalize_against_set": "(x, xs, lindep) orthonormalise x against xs; None when x is linearly dependent",
-    "solve": "(H, b, sigma, x0=None, opType='her', reverseGF=False) solve (sigma*I - H) x = b, "
-             "or (H - sigma*I) x = b with reverseGF",
-    "matrixRepresentation": "(operator, vectors) <v_i| operator |v_j>, host m x m array",
-    "overlapMatrix": "(vectors) <v_i|v_j>, host m x m array",
-    "extendMatrixRepresentation": "(operator, vectors, opMat) append the row and column of vectors[-1]",
-    "extendOverlapMatrix": "(vectors, overlap) append the row and column of vectors[-1]",
-}
+
+class AbstractVector(ABC):
+    """What the solvers may ask of a vector backend."""
+
+    # ---- properties (abstractVector.py:17-37) ------------------------------------------
+    @property
+    @abstractmethod
+    def hasExactAddition(self):
+        """True when adding vectors is exact for this representation (c + c* == 2 Re c);
+        tensor-network backends answer False because their sums are refitted."""
+
+    @property
+    @abstractmethod
+    def dtype(self):
+        """numpy dtype of the coefficients."""
+
+    @property
+    @abstractmethod
+    def maxD(self):
+        """Largest virtual bond dimension (tensor-network backends); 0 for dense storage."""
+
+    # ---- arithmetic (abstractVector.py:39-61) -------------------------------------------
+    @abstractmethod
+    def __mul__(self, other):
+        """Out-of-place scaling by a scalar: a new vector."""
+
+    @abstractmethod
+    def __rmul__(self, other):
+        """scalar * vector: a new vector."""
+
+    @abstractmethod
+    def __truediv__(self, other):
+        """Out-of-place division by a scalar: a new vector."""
+
+    @abstractmethod
+    def __imul__(self, other):
+        """In-place scaling (the array backends raise NotImplementedError)."""
+
+    @abstractmethod
+    def __itruediv__(self, other):
+        """In-place division (the array backends raise NotImplementedError)."""
+
+    @abstractmethod
+    def __len__(self):
+        """Number of coefficients."""
+
+    # ---- instance methods (abstractVector.py:63-97) --------------------------------------
+    @abstractmethod
+    def normalize(self):
+        """Divide by the Euclidean norm in place; returns self."""
+
+    @abstractmethod
+    def norm(self):
+        """Euclidean norm as a host float."""
+
+    @abstractmethod
+    def real(self):
+        """Real part: a new vector."""
+
+    @abstractmethod
+    def conjugate(self):
+        """Complex conjugate: a new vector."""
+
+    @abstractmethod
+    def vdot(self, other, conjugate=True):
+        """<self|other> as a host scalar; self is conjugated unless conjugate=False."""
+
+    @abstractmethod
+    def copy(self):
+        """Deep copy."""
+
+    @abstractmethod
+    def applyOp(self, other):
+        """``other @ self`` as a new vector (``other`` is whatever the backend calls an operator)."""
+
+    @abstractmethod
+    def compress(self):
+        """Compress the representation where that means something; may return self."""
+
+    # ---- static hooks (abstractVector.py:99-169); the defaults raise ---------------------
+    @staticmethod
+    def linearCombination(other, coeff):
+        """sum_n coeff[n] * other[n] as a new vector."""
+        raise NotImplementedError("linearCombination")
+
+    @staticmethod
+    def orthogonalize(xs, lindep=LINDEP_DEFAULT_VALUE):
+        """Orthonormalise a whole set of vectors."""
+        raise NotImplementedError("orthogonalize")
+
+    @staticmethod
+    def orthogonalize_against_set(x, xs, lindep=LINDEP_DEFAULT_VALUE):
+        """Orthonormalise x against the set xs; None when what is left of x has squared norm <= lindep."""
+        raise NotImplementedError("orthogonalize_against_set")
+
+    @staticmethod
+    def solve(H, b, sigma, x0=None, opType="her", reverseGF=False):
+        """x with (sigma*I - H) x = b, or (H - sigma*I) x = b when reverseGF; raises when the
+        backend's iterative solver does not converge."""
+        raise NotImplementedError("solve")
+
+    @staticmethod
+    def matrixRepresentation(operator, vectors):
+        """Host m x m array <v_i| operator |v_j>."""
+        raise NotImplementedError("matrixRepresentation")
+
+    @staticmethod
+    def overlapMatrix(vectors):
+        """Host m x m array <v_i|v_j>."""
+        raise NotImplementedError("overlapMatrix")
+
+    @staticmethod
+    def extendMatrixRepresentation(operator, vectors, opMat):
+        """opMat grown by the row and column that belong to vectors[-1]."""
+        raise NotImplementedError("extendMatrixRepresentation")
+
+    @staticmethod
+    def extendOverlapMatrix(vectors, overlap):
+        """overlap grown by the row and column that belong to vectors[-1]."""
+        raise NotImplementedError("extendOverlapMatrix")
 
 
-def _required(name, contract):
-    def method(self, *args, **kwargs):
-        raise NotImplementedError(name)
-    method.__name__ = method.__qualname__ = name
-    method.__doc__ = contract
-    return abstractmethod(method)
-
-
-def _stub(name, contract):
-    def hook(*args, **kwargs):
-        raise NotImplementedError(name)
-    hook.__name__ = hook.__qualname__ = name
-    hook.__doc__ = contract
-    return staticmethod(hook)
-
-
-def _build():
-    body = {"__doc__": "Abstract vector backend; see PROPERTIES / METHODS / STATIC_HOOKS of this module.",
-            "__module__": __name__}
-    for name, contract in PROPERTIES.items():
-        body[name] = property(_required(name, contract))
-    for name, contract in METHODS.items():
-        body[name] = _required(name, contract)
-    for name, contract in STATIC_HOOKS.items():
-        body[name] = _stub(name, contract)
-    return ABCMeta("AbstractVector", (), body)
-
-
-AbstractVector = _build()
+PROPERTIES = ("hasExactAddition", "dtype", "maxD")
+METHODS = ("__mul__", "__rmul__", "__truediv__", "__imul__", "__itruediv__", "__len__", "normalize", "norm",
+           "real", "conjugate", "vdot", "copy", "applyOp", "compress")
+STATIC_HOOKS = ("linearCombination", "orthogonalize", "orthogonalize_against_set", "solve", "matrixRepresentation",
+                "overlapMatrix", "extendMatrixRepresentation", "extendOverlapMatrix")

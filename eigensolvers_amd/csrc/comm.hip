@@ -31,12 +31,19 @@ struct RcclApi {
 };
 static RcclApi g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
+static char g_rccl_path[512] = "";
+
+// ROCm's own RCCL first: a bare "librccl.so" resolves to whatever copy is already mapped into the
+// process (e.g. the one bundled with a PyTorch wheel, built for another ROCm), which made the library
+// used depend on import order.  HIPEIG_RCCL_LIB overrides the search.
 static int load_rccl() {
   if (g_rccl.handle) return 0;
-  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  const char* names[] = {getenv("HIPEIG_RCCL_LIB"), "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1",
+                         "librccl.so.1", "librccl.so"};
   void* h = nullptr;
   for (const char* nm : names) {
-    h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (!nm || !*nm) continue;
+    h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
     if (h) break;
   }
   if (!h) {
@@ -57,6 +64,8 @@ static int load_rccl() {
   LOAD(GetErrorString, "ncclGetErrorString");
 #undef LOAD
   g_rccl.handle = h;
+  Dl_info di;
+  if (dladdr((void*)g_rccl.AllReduce, &di) && di.dli_fname) snprintf(g_rccl_path, sizeof(g_rccl_path), "%s", di.dli_fname);
   return 0;
 }
 
@@ -193,6 +202,13 @@ static int coll_allgather(hipeig_ctx* c, const void* send, void* recv, size_t co
   return 0;
 }
 
+// Path of the RCCL shared object the collectives run on ("" before the first communicator call).
+extern "C" int hipeig_comm_library(char* path, int path_len) {
+  HIPEIG_REQUIRE(path && path_len > 0, "bad buffer");
+  snprintf(path, (size_t)path_len, "%s", g_rccl_path);
+  return 0;
+}
+
 extern "C" int hipeig_comm_unique_id(void* id128) {
   if (load_rccl()) return 3;
   ncclUniqueId_t id;
@@ -305,6 +321,13 @@ int hipeig_allgather_x(hipeig_ctx* c, const double* x_local, int64_t n_local, in
   if (coll_allgather(c, mine, c->x_full, (size_t)stride, NCCL_FLOAT64, c->stream)) return 4;
   *x_full_out = c->x_full;
   return 0;
+}
+
+// All-gather of `count` doubles per rank into recv (rank r's block at recv + r*count; `send` may be the
+// caller's own block inside recv), on the compute stream.
+int hipeig_allgather_f64(hipeig_ctx* c, const double* send, double* recv, size_t count) {
+  HIPEIG_REQUIRE(c->collectives, "no communicator");
+  return coll_allgather(c, send, recv, count, NCCL_FLOAT64, c->stream);
 }
 
 // Split form of the operand all-gather: `begin` issues the copy + ncclAllGather on the

@@ -82,6 +82,13 @@ struct hipeig_ctx {
   int64_t* row_counts;       // rows per rank (host), length nranks
   double* blk_ws;            // interleaved operand / result blocks of hipeig_spmm
   size_t blk_ws_doubles;
+  double* xb_full;           // all-gathered interleaved operand block ([stride*nranks][8])
+  int64_t xb_full_n;         // its capacity in doubles
+  // block MINRES (minres_block.hip): 7 interleaved blocks and 3 x 8 + 8 recurrence records
+  double* mrb_ws;
+  int64_t mrb_ws_n;
+  MinresState* d_mrb_state;  // ring of 3 x 8 records
+  MinresState* h_mrb_state;  // pinned, 8 records
   int overlap;               // 1: all-gather on the comm stream while the local-column windows are swept
   double* ytmp;              // raw partial sums handed from the local-window launch to the remote one
   int64_t ytmp_n;
@@ -105,6 +112,14 @@ struct hipeig_csr {
   uint32_t* w_off;
   int32_t w_nunits, w_nwin, w_wbits, w_rw, w_wgs_per_sweep;
   int32_t w_csplit;          // workgroups sharing one row block (column splits), 1 = none
+  // block-operand copy ("TCOO-B", spmm_device.h): units sized for 8 accumulators per row; built on first use
+  uint32_t* b_idx;
+  double* b_val;
+  uint32_t* b_off;
+  int32_t b_nunits, b_nwin, b_wbits, b_rw, b_wgs_per_sweep;
+  int32_t b_state;           // 0 = undecided, 1 = built, 2 = not suited (row-owner kernel is used)
+  int32_t block_variant;     // 0 = automatic, 1 = row-owner CSR, 2 = TCOO-B
+  int32_t last_block_variant;
   int64_t gather_len;        // length of the gathered operand (ncols, or stride*nranks)
   int variant;               // 0 = auto, 1 = CSR-vector, 2 = CSR-stream, 3 = TCOO (wave units), 4 = TCOO-W
   int last_variant;          // variant used by the most recent launch (0 = none yet)
@@ -119,6 +134,7 @@ int hipeig_comm_setup_rows(hipeig_ctx* ctx, int64_t nrows_local, int64_t* stride
 int hipeig_allreduce_sum(hipeig_ctx* ctx, double* d_buf, int count);
 int hipeig_allgather_x(hipeig_ctx* ctx, const double* x_local, int64_t n_local, int64_t stride,
                        const double** x_full_out);
+int hipeig_allgather_f64(hipeig_ctx* ctx, const double* send, double* recv, size_t count);
 int hipeig_allgather_x_begin(hipeig_ctx* ctx, const double* x_local, int64_t n_local, int64_t stride);
 int hipeig_allgather_x_end(hipeig_ctx* ctx, const double** x_full_out);
 

@@ -79,6 +79,10 @@ extern "C" int hipeig_ctx_destroy(hipeig_ctx* c) {
   if (c->x_full) hipFree(c->x_full);
   if (c->ytmp) hipFree(c->ytmp);
   if (c->blk_ws) hipFree(c->blk_ws);
+  if (c->xb_full) hipFree(c->xb_full);
+  if (c->mrb_ws) hipFree(c->mrb_ws);
+  if (c->d_mrb_state) hipFree(c->d_mrb_state);
+  if (c->h_mrb_state) hipHostFree(c->h_mrb_state);
   free(c->row_counts);
   hipEventDestroy(c->ev0);
   hipEventDestroy(c->ev1);

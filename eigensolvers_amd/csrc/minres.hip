@@ -26,44 +26,7 @@ int hipeig_spmv_grid(const hipeig_csr* A, int variant);
 int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A);
 size_t hipeig_tcoo_lds_bytes(const hipeig_csr* A);
 
-#define MR_EPS 2.220446049250313e-16
-
-struct MinresArgs {
-  double sigma, sign, rtol;
-  int maxiter;
-  int nA, nC, nD;                 // number of valid partials of KA / KC / KD (1 = already reduced)
-  const double* pA; const double* pC; const double* pD;
-};
-
-__device__ __forceinline__ double sum_or_value(const double* p, int count, double* lds) {
-  if (count == 1) return p[0];
-  return block_sum_partials(p, count, lds);
-}
-
-// Stopping tests of the iteration that has just completed (SciPy order).  S is a private copy.
-__device__ __forceinline__ void minres_tests(MinresState& S, double xx, const MinresArgs& a) {
-  if (S.itn == 0 || S.done) return;
-  S.Anorm = sqrt(S.tnorm2);
-  S.ynorm = sqrt(xx);
-  const double epsx = S.Anorm * S.ynorm * MR_EPS;
-  S.rnorm = S.phibar;
-  S.test1 = (S.ynorm == 0.0 || S.Anorm == 0.0) ? INFINITY : S.rnorm / (S.Anorm * S.ynorm);
-  S.test2 = (S.Anorm == 0.0) ? INFINITY : S.root / S.Anorm;
-  S.Acond = S.gmax / S.gmin;
-  int istop = S.pending_m1 ? -1 : 0;
-  if (istop == 0) {
-    const double t1 = 1.0 + S.test1, t2 = 1.0 + S.test2;
-    if (t2 <= 1.0) istop = 2;
-    if (t1 <= 1.0) istop = 1;
-    if (S.itn >= a.maxiter) istop = 6;
-    if (S.Acond >= 0.1 / MR_EPS) istop = 4;
-    if (epsx >= S.beta1) istop = 3;
-    if (S.test2 <= a.rtol) istop = 2;
-    if (S.test1 <= a.rtol) istop = 1;
-  }
-  S.istop = istop;
-  if (istop != 0) S.done = 1;
-}
+#include "minres_device.h"
 
 struct MinresRowEpilogue {
   double sigma, sign, s, c1;
@@ -156,27 +119,7 @@ minres_kd_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, M
   }
   const double bb = sum_or_value(a.pC, a.nC, red);
   const double s_old = S.s;
-  // ---- scalar recurrences (every thread, identical) ----
-  S.oldb = S.beta;
-  S.beta = sqrt(bb);
-  S.tnorm2 += S.alfa * S.alfa + S.oldb * S.oldb + S.beta * S.beta;
-  if (S.itn == 0 && S.beta / S.beta1 <= 10.0 * MR_EPS) S.pending_m1 = 1;
-  S.oldeps = S.epsln;
-  S.delta = S.cs * S.dbar + S.sn * S.alfa;
-  S.gbar = S.sn * S.dbar - S.cs * S.alfa;
-  S.epsln = S.sn * S.beta;
-  S.dbar = -S.cs * S.beta;
-  S.root = sqrt(S.gbar * S.gbar + S.dbar * S.dbar);
-  S.gamma = fmax(sqrt(S.gbar * S.gbar + S.beta * S.beta), MR_EPS);
-  S.cs = S.gbar / S.gamma;
-  S.sn = S.beta / S.gamma;
-  S.phi = S.cs * S.phibar;
-  S.phibar = S.sn * S.phibar;
-  S.denom = 1.0 / S.gamma;
-  S.gmax = fmax(S.gmax, S.gamma);
-  S.gmin = fmin(S.gmin, S.gamma);
-  S.s = 1.0 / S.beta;
-  S.itn += 1;
+  minres_advance(S, bb);      // scalar recurrences (every thread, identical)
   if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
   // ---- w = (v - oldeps*w1 - delta*w2)*denom ; x += phi*w ----
   const double oldeps = S.oldeps, delta = S.delta, denom = S.denom, phi = S.phi;
@@ -256,13 +199,7 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   HIPEIG_CHECK(hipMemsetAsync(W[0], 0, (size_t)npad * 4 * sizeof(double), c->stream));   // W[0..2] and xw
 
   MinresState* h = c->h_mr_state;
-  memset(h, 0, sizeof(MinresState));
-  h->beta1 = sqrt(bb);
-  h->beta = h->beta1;
-  h->phibar = h->beta1;
-  h->cs = -1.0;
-  h->gmin = 1.7976931348623157e308;
-  h->s = 1.0 / h->beta;
+  minres_init_state(h, bb);
   MinresState* V = c->d_mr_state;
   HIPEIG_CHECK(hipMemcpyAsync(V, h, sizeof(MinresState), hipMemcpyHostToDevice, c->stream));
   // the pinned record is rewritten by the first chunk's copy-back; the upload above must have read it

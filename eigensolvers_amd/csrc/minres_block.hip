@@ -1,0 +1,342 @@
+// Lock-step block MINRES: the nBlock inner solves of one block-Lanczos iteration
+// (inexact_Lanczos.py:319-320 calls typeClass.solve once per block vector, on the same operator
+// and shift; feast.py:189-201 does the same for the m0 right-hand sides of a contour point)
+// advanced TOGETHER, one tall-skinny block product per iteration instead of nBlock operator sweeps.
+//
+// Every column runs exactly the recurrences of the single-vector driver (minres.hip; the scalar
+// code is shared through minres_device.h): its own MinresState record, its own stopping tests in
+// SciPy's order, its own iteration count.  A column that has stopped is masked: its iterate is no
+// longer touched, so what is returned for it is the iterate of the iteration it stopped at, as
+// scipy.sparse.linalg.minres (numpyVector.py:163) would return it.  All vectors are interleaved
+// blocks ([row][8]); one iteration = three kernels like the single-vector driver:
+//   KA  Y = A V - (beta/oldb) R1, V = R2/beta    (block product, fused)  + partials <v_j, y_j>
+//   KC  Y -= (alfa/beta) R2                                               + partials <y_j, y_j>
+//   KD  W = (V - oldeps W1 - delta W2)/gamma ; X += phi W                  + partials <x_j, x_j>
+#include "minres_device.h"
+#include "spmm_device.h"
+
+int hipeig_block_pick_variant(hipeig_ctx* c, hipeig_csr* A);
+BcooView hipeig_bcoo_view(const hipeig_csr* A);
+size_t hipeig_bcoo_lds_bytes(const hipeig_csr* A);
+int hipeig_block_allgather(hipeig_ctx* c, hipeig_csr* A, const double* xb_local, const double** xb_full);
+int hipeig_block_pack(hipeig_ctx* c, int64_t n, int k, const double* const* cols, double* blk);
+int hipeig_block_unpack(hipeig_ctx* c, int64_t n, int k, const double* blk, double* const* cols);
+int hipeig_rowowner_grid(const hipeig_ctx* c, const hipeig_csr* A);
+
+#define MRB_PART_STRIDE (HIPEIG_MAX_PARTIALS * BCOO_K)     // doubles between the three partial areas
+
+// Per-operand sum of `count` partial records for the operand threadIdx.x % 8 (count == 1: the record
+// has already been reduced, e.g. by an all-reduce).
+__device__ __forceinline__ double sum_or_value_cols8(const double* p, int count, double* lds) {
+  if (count == 1) return p[threadIdx.x & 7];
+  return block_sum_partials_cols8(p, count, lds);
+}
+
+struct MinresBlockEpilogue {
+  double sigma, sign, s, c1;         // s, c1: the scalars of THIS thread's operand (threadIdx.x % 8)
+  int use_r1;
+  const double* __restrict__ r2l;    // local rows of R2 (v = s*r2)
+  const double* __restrict__ r1;
+  double* __restrict__ y;
+  __device__ __forceinline__ void elem(int64_t r, int j, double sum, double& acc) const {
+    const int64_t i = r * BCOO_K + j;
+    const double v = s * r2l[i];
+    double yv = sign * (mul_rn(sigma, v) - s * sum);
+    if (use_r1) yv -= c1 * r1[i];
+    y[i] = yv;
+    acc = fma(v, yv, acc);
+  }
+};
+
+// VARIANT 2: window-blocked (TCOO-B) sweep, 1024 threads; VARIANT 1: row-owner CSR sweep, 256 threads.
+template <int VARIANT>
+__global__ void __launch_bounds__(VARIANT == 2 ? BCOO_THREADS : HIPEIG_BLOCK)
+minres_block_ka_kernel(BcooView T, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                       const double* __restrict__ val, int64_t nrows, const double* __restrict__ xg, MinresArgs a,
+                       const MinresState* __restrict__ Sin, MinresState* __restrict__ Sout,
+                       const double* __restrict__ r2l, const double* __restrict__ r1, double* __restrict__ y,
+                       double* __restrict__ partials) {
+  __shared__ double red[(VARIANT == 2 ? BCOO_THREADS : HIPEIG_BLOCK) / 64 * 8];
+  __shared__ double sh_s[8], sh_c1[8];
+  __shared__ int sh_use[8], sh_live;
+  extern __shared__ double bcoo_lds[];
+  const double xx = sum_or_value_cols8(a.pD, a.nD, red);
+  if (threadIdx.x == 0) sh_live = 0;
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    MinresState S = Sin[threadIdx.x];
+    minres_tests(S, (S.itn > 0 && !S.done) ? xx : 0.0, a);
+    if (blockIdx.x == 0) Sout[threadIdx.x] = S;
+    const int use = (!S.done && S.itn >= 1);
+    sh_s[threadIdx.x] = S.done ? 0.0 : S.s;
+    sh_c1[threadIdx.x] = use ? S.beta / S.oldb : 0.0;
+    sh_use[threadIdx.x] = use;
+    if (!S.done) atomicOr(&sh_live, 1);
+  }
+  __syncthreads();
+  if (!sh_live) return;                                   // every column has stopped
+  MinresBlockEpilogue epi;
+  const int j = threadIdx.x & 7;
+  epi.sigma = a.sigma; epi.sign = a.sign; epi.s = sh_s[j]; epi.c1 = sh_c1[j]; epi.use_r1 = sh_use[j];
+  epi.r2l = r2l; epi.r1 = r1; epi.y = y;
+  double acc = 0.0;
+  if (VARIANT == 2) bcoo_wg_sweep(T, xg, epi, acc, bcoo_lds);
+  else csr_rowowner_block_sweep(rowptr, col, val, nrows, xg, epi, acc);
+  const double tot = block_reduce_cols8(acc, red);
+  if (threadIdx.x < 8) partials[(size_t)blockIdx.x * BCOO_K + threadIdx.x] = tot;
+}
+
+// Fold (a0, a1) - partials of operands 2(t%4) and 2(t%4)+1 - over the workgroup; record in threads 0..7.
+__device__ __forceinline__ void block_reduce_pairs(double a0, double a1, double* lds, double* __restrict__ out_record) {
+#pragma unroll
+  for (int off = 4; off < 64; off <<= 1) {
+    a0 += __shfl_xor(a0, off, 64);
+    a1 += __shfl_xor(a1, off, 64);
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane < 4) { lds[wid * 8 + lane * 2] = a0; lds[wid * 8 + lane * 2 + 1] = a1; }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    double r = lds[threadIdx.x];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r += lds[w * 8 + threadIdx.x];
+    out_record[threadIdx.x] = r;
+  }
+}
+
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+minres_block_kc_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, MinresState* __restrict__ Sout,
+                       const double* __restrict__ r2, double* __restrict__ y, double* __restrict__ partials) {
+  __shared__ double red[HIPEIG_BLOCK / 64 * 8];
+  __shared__ double sh_c[8];
+  const double alfa = sum_or_value_cols8(a.pA, a.nA, red);
+  if (threadIdx.x < 8) {
+    MinresState S = Sin[threadIdx.x];
+    if (!S.done) S.alfa = alfa;
+    if (blockIdx.x == 0) Sout[threadIdx.x] = S;
+    sh_c[threadIdx.x] = S.done ? 0.0 : S.alfa / S.beta;
+  }
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;           // multiple of 4: operand pair fixed per thread
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int j0 = (int)(t0 & 3) * 2;
+  const double c0 = sh_c[j0], c1 = sh_c[j0 + 1];
+  const double2* r22 = reinterpret_cast<const double2*>(r2);
+  double2* y2 = reinterpret_cast<double2*>(y);
+  double a0 = 0.0, a1 = 0.0;
+  for (int64_t t = t0; t < n * 4; t += stride) {
+    const double2 rv = r22[t];
+    double2 yv = y2[t];
+    yv.x -= c0 * rv.x; yv.y -= c1 * rv.y;
+    y2[t] = yv;
+    a0 = fma(yv.x, yv.x, a0); a1 = fma(yv.y, yv.y, a1);
+  }
+  block_reduce_pairs(a0, a1, red, partials + (size_t)blockIdx.x * BCOO_K);
+}
+
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+minres_block_kd_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, MinresState* __restrict__ Sout,
+                       const double* __restrict__ r2old, const double* __restrict__ w1, const double* __restrict__ w2,
+                       double* __restrict__ w, double* __restrict__ x, double* __restrict__ partials) {
+  __shared__ double red[HIPEIG_BLOCK / 64 * 8];
+  __shared__ double sh_sold[8], sh_oldeps[8], sh_delta[8], sh_denom[8], sh_phi[8];
+  __shared__ int sh_done[8];
+  const double bb = sum_or_value_cols8(a.pC, a.nC, red);
+  if (threadIdx.x < 8) {
+    MinresState S = Sin[threadIdx.x];
+    sh_sold[threadIdx.x] = S.s;
+    if (!S.done) minres_advance(S, bb);
+    if (blockIdx.x == 0) Sout[threadIdx.x] = S;
+    sh_oldeps[threadIdx.x] = S.oldeps; sh_delta[threadIdx.x] = S.delta;
+    sh_denom[threadIdx.x] = S.denom; sh_phi[threadIdx.x] = S.phi;
+    sh_done[threadIdx.x] = S.done;
+  }
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int j0 = (int)(t0 & 3) * 2, j1 = j0 + 1;
+  const double s0 = sh_sold[j0], e0 = sh_oldeps[j0], d0 = sh_delta[j0], q0 = sh_denom[j0], p0 = sh_phi[j0];
+  const double s1 = sh_sold[j1], e1 = sh_oldeps[j1], d1 = sh_delta[j1], q1 = sh_denom[j1], p1 = sh_phi[j1];
+  const bool live0 = !sh_done[j0], live1 = !sh_done[j1];
+  const double2* r2 = reinterpret_cast<const double2*>(r2old);
+  const double2* w12 = reinterpret_cast<const double2*>(w1);
+  const double2* w22 = reinterpret_cast<const double2*>(w2);
+  double2* wn2 = reinterpret_cast<double2*>(w);
+  double2* x2 = reinterpret_cast<double2*>(x);
+  double a0 = 0.0, a1 = 0.0;
+  if (live0 || live1) {
+    for (int64_t t = t0; t < n * 4; t += stride) {
+      const double2 rv = r2[t], b1 = w12[t], b2 = w22[t];
+      double2 xv = x2[t], wn = wn2[t];
+      if (live0) { wn.x = (s0 * rv.x - e0 * b1.x - d0 * b2.x) * q0; xv.x += p0 * wn.x; }
+      if (live1) { wn.y = (s1 * rv.y - e1 * b1.y - d1 * b2.y) * q1; xv.y += p1 * wn.y; }
+      wn2[t] = wn;
+      x2[t] = xv;
+      a0 = fma(xv.x, xv.x, a0); a1 = fma(xv.y, xv.y, a1);
+    }
+  }
+  block_reduce_pairs(a0, a1, red, partials + (size_t)blockIdx.x * BCOO_K);
+}
+
+// End-of-chunk evaluation of the stopping tests (what KA's prologue would do next).
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+minres_block_check_kernel(MinresArgs a, MinresState* __restrict__ S0) {
+  __shared__ double red[HIPEIG_BLOCK / 64 * 8];
+  const double xx = sum_or_value_cols8(a.pD, a.nD, red);
+  if (threadIdx.x < 8) {
+    MinresState S = S0[threadIdx.x];
+    minres_tests(S, (S.itn > 0 && !S.done) ? xx : 0.0, a);
+    S0[threadIdx.x] = S;
+  }
+}
+
+// one record of 8 per-operand sums from `count` partial records (distributed path, before the all-reduce)
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+sum_partials_cols8_kernel(const double* __restrict__ p, int count, double* __restrict__ out) {
+  __shared__ double red[HIPEIG_BLOCK / 64 * 8];
+  const double v = block_sum_partials_cols8(p, count, red);
+  if (threadIdx.x < 8) out[threadIdx.x] = v;
+}
+
+extern "C" int hipeig_minres_block(hipeig_ctx* c, hipeig_csr* A, double sigma, double sign, int k,
+                                   const double* const* b, double* const* x, double rtol, int maxiter,
+                                   int* info, double* out_stats) {
+  HIPEIG_REQUIRE(info != nullptr && b != nullptr && x != nullptr, "null argument");
+  HIPEIG_REQUIRE(k >= 1 && k <= BCOO_K, "a block solve takes 1..8 right-hand sides");
+  HIPEIG_REQUIRE(sign == 1.0 || sign == -1.0, "sign must be +1 or -1");
+  HIPEIG_REQUIRE(maxiter >= 1, "maxiter must be positive");
+  HIPEIG_REQUIRE(c->collectives || A->nrows == A->ncols, "the inner solve needs a square operator (or a row partition)");
+  const int64_t n = A->nrows;
+  for (int j = 0; j < k; ++j) {
+    info[j] = 0;
+    HIPEIG_REQUIRE(b[j] != x[j], "x must not alias b");
+  }
+  if (out_stats) memset(out_stats, 0, (size_t)k * 8 * sizeof(double));
+  if (n == 0) return 0;
+
+  // recurrence records: <b_j, b_j> with the same reduction as the single-vector driver
+  if (!c->d_mrb_state) {
+    HIPEIG_CHECK(hipMalloc((void**)&c->d_mrb_state, 3 * BCOO_K * sizeof(MinresState)));
+    HIPEIG_CHECK(hipHostMalloc((void**)&c->h_mrb_state, BCOO_K * sizeof(MinresState), hipHostMallocDefault));
+  }
+  MinresState* h = c->h_mrb_state;
+  int live = 0;
+  for (int j = 0; j < BCOO_K; ++j) {
+    double bb = 0.0;
+    if (j < k && hipeig_dot(c, n, b[j], b[j], &bb)) return 1;
+    if (bb > 0.0) { minres_init_state(&h[j], bb); ++live; }
+    else {                                   // padding column, or beta1 == 0: the exact solution is x0 = 0
+      memset(&h[j], 0, sizeof(MinresState));
+      h[j].done = 1;
+    }
+  }
+  if (live == 0) {
+    for (int j = 0; j < k; ++j) if (hipeig_vec_fill(c, x[j], n, 0.0)) return 1;
+    return 0;
+  }
+
+  // workspace: R[3] (r1, r2, y rotate), W[3] (w1, w2, w rotate) and the iterate block
+  const int64_t nb = n * BCOO_K;
+  if (c->mrb_ws_n < nb) {
+    if (c->mrb_ws) HIPEIG_CHECK(hipFree(c->mrb_ws));
+    c->mrb_ws = nullptr; c->mrb_ws_n = 0;
+    HIPEIG_CHECK(hipMalloc((void**)&c->mrb_ws, (size_t)nb * 7 * sizeof(double)));
+    c->mrb_ws_n = nb;
+  }
+  double* R[3] = {c->mrb_ws, c->mrb_ws + c->mrb_ws_n, c->mrb_ws + 2 * c->mrb_ws_n};
+  double* W[3] = {c->mrb_ws + 3 * c->mrb_ws_n, c->mrb_ws + 4 * c->mrb_ws_n, c->mrb_ws + 5 * c->mrb_ws_n};
+  double* xw = c->mrb_ws + 6 * c->mrb_ws_n;
+  if (hipeig_block_pack(c, n, k, b, R[0])) return 1;
+  HIPEIG_CHECK(hipMemsetAsync(R[1], 0, (size_t)c->mrb_ws_n * 6 * sizeof(double), c->stream));
+  MinresState* V = c->d_mrb_state;
+  HIPEIG_CHECK(hipMemcpyAsync(V, h, BCOO_K * sizeof(MinresState), hipMemcpyHostToDevice, c->stream));
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));       // the pinned records are rewritten by the first copy-back
+
+  const int bv = hipeig_block_pick_variant(c, A);
+  if (bv < 0) return 1;
+  const BcooView tview = hipeig_bcoo_view(A);
+  if (bv == 2)
+    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_block_ka_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)HIPEIG_BCOO_LDS_MAX));
+  const int gA = (bv == 2) ? (A->b_wgs_per_sweep < A->b_nunits ? A->b_wgs_per_sweep : A->b_nunits) : hipeig_rowowner_grid(c, A);
+  const int nsweepA = (bv == 2) ? (A->b_nunits + gA - 1) / gA : 1;
+  HIPEIG_REQUIRE((int64_t)nsweepA * gA <= HIPEIG_MAX_PARTIALS, "too many sweeps for the partial-sum buffer");
+  const int gE = grid_for(n * 4, 4);
+  double* pA = c->d_partials;
+  double* pC = c->d_partials + MRB_PART_STRIDE;
+  double* pD = c->d_partials + 2 * MRB_PART_STRIDE;
+  HIPEIG_REQUIRE(c->partials_doubles >= (size_t)3 * MRB_PART_STRIDE, "partial-sum workspace too small");
+  const bool dist = c->collectives != 0;
+  double* red = c->d_scalars + 2048;                  // three reduced records of 8 for the distributed path
+  MinresArgs a;
+  a.sigma = sigma; a.sign = sign; a.rtol = rtol; a.maxiter = maxiter;
+  const int nPA = gA * nsweepA;
+  a.pA = dist ? red + 0 : pA; a.nA = dist ? 1 : nPA;
+  a.pC = dist ? red + 8 : pC; a.nC = dist ? 1 : gE;
+  a.pD = dist ? red + 16 : pD; a.nD = dist ? 1 : gE;
+  if (dist) HIPEIG_CHECK(hipMemsetAsync(red, 0, 24 * sizeof(double), c->stream));
+
+  auto enqueue_iteration = [&](int it) -> int {
+    double* r2 = R[it % 3];
+    double* yb = R[(it + 1) % 3];
+    double* r1 = R[(it + 2) % 3];
+    double* wn = W[it % 3];
+    double* w1 = W[(it + 1) % 3];
+    double* w2 = W[(it + 2) % 3];
+    const double* xg = nullptr;
+    if (hipeig_block_allgather(c, A, r2, &xg)) return 4;
+    if (bv == 2) {
+      BcooView tv = tview;
+      for (int sw = 0; sw < nsweepA; ++sw) {
+        tv.unit_begin = sw * gA;
+        hipLaunchKernelGGL((minres_block_ka_kernel<2>), dim3(gA), dim3(BCOO_THREADS), hipeig_bcoo_lds_bytes(A), c->stream,
+                           tv, A->d_rowptr, A->d_col, A->d_val, n, xg, a, V + 0, V + 8, r2, r1, yb, pA + (size_t)sw * gA * BCOO_K);
+      }
+    } else {
+      hipLaunchKernelGGL((minres_block_ka_kernel<1>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream,
+                         tview, A->d_rowptr, A->d_col, A->d_val, n, xg, a, V + 0, V + 8, r2, r1, yb, pA);
+    }
+    if (dist) {
+      hipLaunchKernelGGL(sum_partials_cols8_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pA, nPA, red + 0);
+      if (hipeig_allreduce_sum(c, red + 0, 8)) return 4;
+    }
+    hipLaunchKernelGGL(minres_block_kc_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 8, V + 16, r2, yb, pC);
+    if (dist) {
+      hipLaunchKernelGGL(sum_partials_cols8_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pC, gE, red + 8);
+      if (hipeig_allreduce_sum(c, red + 8, 8)) return 4;
+    }
+    hipLaunchKernelGGL(minres_block_kd_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 16, V + 0, r2, w1, w2, wn, xw, pD);
+    if (dist) {
+      hipLaunchKernelGGL(sum_partials_cols8_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pD, gE, red + 16);
+      if (hipeig_allreduce_sum(c, red + 16, 8)) return 4;
+    }
+    return 0;
+  };
+
+  const int chunk = 16;
+  int it = 0;
+  bool all_done = false;
+  while (it < maxiter && !all_done) {
+    const int iend = (it + chunk < maxiter) ? it + chunk : maxiter;
+    for (; it < iend; ++it) {
+      const int rc = enqueue_iteration(it);
+      if (rc) return rc;
+    }
+    HIPEIG_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(minres_block_check_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, a, V + 0);
+    HIPEIG_CHECK(hipMemcpyAsync(h, V, BCOO_K * sizeof(MinresState), hipMemcpyDeviceToHost, c->stream));
+    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+    all_done = true;
+    for (int j = 0; j < BCOO_K; ++j) all_done = all_done && h[j].done;
+  }
+  HIPEIG_REQUIRE(all_done, "block MINRES left the iteration loop without a stop code in every column");
+  if (hipeig_block_unpack(c, n, k, xw, x)) return 1;
+  for (int j = 0; j < k; ++j) {
+    info[j] = (h[j].istop == 6) ? maxiter : 0;
+    if (out_stats) {
+      double* st = out_stats + (size_t)j * 8;
+      st[0] = h[j].itn; st[1] = h[j].istop; st[2] = h[j].rnorm; st[3] = h[j].Anorm;
+      st[4] = h[j].ynorm; st[5] = h[j].test1; st[6] = h[j].test2; st[7] = h[j].Acond;
+    }
+  }
+  return 0;
+}

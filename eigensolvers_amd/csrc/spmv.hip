@@ -249,87 +249,6 @@ extern "C" int hipeig_spmv_shift(hipeig_ctx* c, hipeig_csr* A, double sigma, dou
   return launch_spmv(c, A, sign * sigma, -sign, x, y);
 }
 
-// ---- block product Y = H X for k <= 16 operands (tall-skinny SpMM) --------------------------
-// matrixRepresentation (numpyVector.py:180-190) applies H to every basis vector; with the k
-// operands interleaved ([row][k], 8k bytes contiguous per row) one column index and one value
-// serve k FMAs and the gather per non-zero is ONE contiguous 8k-byte read instead of k scattered
-// 8-byte reads.  A wavefront owns one row at a time: lane = (slot s, operand r), KP = 8 or 16
-// operand lanes, 64/KP non-zeros in flight; partial sums over the slots are folded with shuffles.
-struct PtrTable16 { const double* p[16]; };
-struct OutTable16 { double* p[16]; };
-
-__global__ void __launch_bounds__(HIPEIG_BLOCK)
-pack_kernel(int64_t n, int k, int kp, PtrTable16 cols, double* __restrict__ out) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    for (int j = 0; j < kp; ++j) out[i * kp + j] = (j < k) ? cols.p[j][i] : 0.0;
-}
-
-__global__ void __launch_bounds__(HIPEIG_BLOCK)
-unpack_kernel(int64_t n, int k, int kp, const double* __restrict__ in, OutTable16 cols) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    for (int j = 0; j < k; ++j) cols.p[j][i] = in[i * kp + j];
-}
-
-template <int KP>
-__global__ void __launch_bounds__(HIPEIG_BLOCK)
-spmm_kernel(CsrView A, const double* __restrict__ X, double* __restrict__ Y) {
-  constexpr int SLOTS = 64 / KP;
-  const int lane = threadIdx.x & 63;
-  const int r = lane % KP, sl = lane / KP;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t row = wave; row < A.nrows; row += nwaves) {
-    const int s = A.rowptr[row], e = A.rowptr[row + 1];
-    double acc = 0.0;
-    for (int p = s + sl; p < e; p += SLOTS)
-      acc = fma(__builtin_nontemporal_load(A.val + p), X[(int64_t)__builtin_nontemporal_load(A.col + p) * KP + r], acc);
-#pragma unroll
-    for (int off = 32; off >= KP; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if (sl == 0) Y[row * KP + r] = acc;
-  }
-}
-
-extern "C" int hipeig_spmm(hipeig_ctx* c, hipeig_csr* A, int k, const double* const* X, double* const* Y) {
-  HIPEIG_REQUIRE(k >= 1 && X && Y, "bad arguments");
-  if (A->nrows == 0) return 0;
-  if (c->collectives || A->nrows != A->ncols) {       // partitioned / slab operators: operand by operand
-    for (int j = 0; j < k; ++j)
-      if (hipeig_spmv(c, A, X[j], Y[j])) return 1;
-    return 0;
-  }
-  const int64_t n = A->nrows;
-  for (int j0 = 0; j0 < k; j0 += 16) {
-    const int kk = (k - j0 < 16) ? k - j0 : 16;
-    const int kp = kk <= 8 ? 8 : 16;
-    const size_t need = (size_t)2 * n * kp;
-    if (c->blk_ws_doubles < need) {
-      if (c->blk_ws) HIPEIG_CHECK(hipFree(c->blk_ws));
-      c->blk_ws = nullptr; c->blk_ws_doubles = 0;
-      HIPEIG_CHECK(hipMalloc((void**)&c->blk_ws, need * sizeof(double)));
-      c->blk_ws_doubles = need;
-    }
-    double* Xi = c->blk_ws;
-    double* Yi = c->blk_ws + (size_t)n * kp;
-    PtrTable16 xin;
-    OutTable16 yout;
-    for (int j = 0; j < 16; ++j) { xin.p[j] = j < kk ? X[j0 + j] : nullptr; yout.p[j] = j < kk ? Y[j0 + j] : nullptr; }
-    const int ge = grid_for(n, 1);
-    hipLaunchKernelGGL(pack_kernel, dim3(ge), dim3(HIPEIG_BLOCK), 0, c->stream, n, kk, kp, xin, Xi);
-    const CsrView v = hipeig_csr_view(A);
-    int64_t g = (n + 3) / 4;
-    if (g > 8 * (int64_t)c->num_cu) g = 8 * (int64_t)c->num_cu;
-    if (kp == 8)
-      hipLaunchKernelGGL((spmm_kernel<8>), dim3((int)g), dim3(HIPEIG_BLOCK), 0, c->stream, v, Xi, Yi);
-    else
-      hipLaunchKernelGGL((spmm_kernel<16>), dim3((int)g), dim3(HIPEIG_BLOCK), 0, c->stream, v, Xi, Yi);
-    hipLaunchKernelGGL(unpack_kernel, dim3(ge), dim3(HIPEIG_BLOCK), 0, c->stream, n, kk, kp, Yi, yout);
-    HIPEIG_CHECK(hipGetLastError());
-  }
-  return 0;
-}
-
 // ---- TCOO construction -------------------------------------------------------------------
 // One workgroup per unit (RW consecutive rows), rows handled in chunks of 256 (one row per
 // thread).  count pass: non-zeros per (unit, window).  fill pass: a non-zero of row r and
@@ -730,6 +649,9 @@ extern "C" int hipeig_csr_destroy(hipeig_ctx* c, hipeig_csr* A) {
   if (A->w_idx) hipFree(A->w_idx);
   if (A->w_val) hipFree(A->w_val);
   if (A->w_off) hipFree(A->w_off);
+  if (A->b_idx) hipFree(A->b_idx);
+  if (A->b_val) hipFree(A->b_val);
+  if (A->b_off) hipFree(A->b_off);
   free(A);
   return 0;
 }

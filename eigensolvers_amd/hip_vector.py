@@ -207,6 +207,18 @@ class HipCsrOperator:
         _lib.call("hipeig_csr_info", self.handle, info)
         return self.VARIANTS[int(info[4])]
 
+    BLOCK_VARIANTS = {0: "none", 1: "row-owner", 2: "column-window-blocked"}
+
+    def set_block_variant(self, variant):
+        """Kernel of the block product / block solve: 0 automatic, 1 row-owner CSR, 2 window-blocked."""
+        _lib.call("hipeig_csr_set_block_variant", self.handle, int(variant))
+
+    def block_info(self):
+        info = (C.c_int64 * 4)()
+        _lib.call("hipeig_csr_block_info", self.handle, info)
+        return {"variant": self.BLOCK_VARIANTS[int(info[0])], "row_blocks": int(info[1]), "windows": int(info[2]),
+                "rows_per_block": int(info[3])}
+
     def launches_per_apply(self):
         """Kernel launches (sweeps) one product takes with the variant last used."""
         info = (C.c_int64 * 8)()
@@ -277,8 +289,9 @@ class HipVector(AbstractVector):
         lsa.setdefault("linear_tol", 1e-4)
         lsa.setdefault("linear_atol", 1e-4)
         self.options = {"linearSystemArgs": lsa}
-        if "orthogonalization" in given:
-            self.options["orthogonalization"] = given["orthogonalization"]
+        for extra in ("orthogonalization", "blockSolve"):
+            if extra in given:
+                self.options[extra] = given[extra]
         self.last_solve_stats = None
 
     # ---- helpers -------------------------------------------------------------------
@@ -465,6 +478,42 @@ class HipVector(AbstractVector):
             # numpyVector.py:175-177: the warning is escalated to an exception
             raise UserWarning("Warning:: Iterative solver is not converged ")
         return res
+
+    @staticmethod
+    def solveBlock(H, bs, sigma, x0=None, opType="her", reverseGF=False):
+        """``[solve(H, b, sigma) for b in bs]`` with the solves advanced in lock step: one block product
+        per MINRES iteration for up to 8 right-hand sides (inexact_Lanczos.py:319-320 calls ``solve``
+        once per block vector on the same operator and shift).  Every column runs the recurrences and
+        stopping tests of the single solve; results, ``last_solve_stats`` and the exception on
+        non-convergence (numpyVector.py:175-177) are those of the one-by-one calls.  Solvers other
+        than MINRES and complex shifts fall back to the one-by-one calls."""
+        bs = list(bs)
+        o = bs[0].options["linearSystemArgs"]
+        if (o["linearSolver"] != "minres" or isinstance(sigma, complex) or np.iscomplexobj(sigma)
+                or x0 is not None or len(bs) == 1 or not isinstance(H, HipCsrOperator)):
+            return [HipVector.solve(H, b, sigma, x0, opType, reverseGF) for b in bs]
+        ctx, n = bs[0].ctx, bs[0]._buf.n
+        results = []
+        for i0 in range(0, len(bs), 8):
+            chunk = bs[i0:i0 + 8]
+            k = len(chunk)
+            outs = [ctx.alloc(n) for _ in chunk]
+            bt, keep1 = _ptr_table([b._buf for b in chunk])
+            xt, keep2 = _ptr_table(outs)
+            info = (C.c_int * k)()
+            stats = (C.c_double * (8 * k))()
+            _lib.call("hipeig_minres_block", ctx.handle, H.handle, float(sigma), -1.0 if reverseGF else 1.0, k,
+                      bt, xt, float(o["linear_tol"]), int(o["linearIter"]), info, stats)
+            for j, b in enumerate(chunk):
+                res = b._new(outs[j])
+                st = stats[8 * j:8 * j + 8]
+                res.last_solve_stats = b.last_solve_stats = {
+                    "iterations": int(st[0]), "istop": int(st[1]), "rnorm": st[2], "Anorm": st[3],
+                    "ynorm": st[4], "test1": st[5], "test2": st[6], "Acond": st[7]}
+                results.append(res)
+            if any(info[j] != 0 for j in range(k)):
+                raise UserWarning("Warning:: Iterative solver is not converged ")
+        return results
 
     @staticmethod
     def _solve_complex(H, b, z, o, reverseGF):

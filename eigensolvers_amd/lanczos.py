@@ -55,30 +55,59 @@ def _new_status(user_status, guess, nBlock):
 
 
 class _SummaryWriter:
-    """Minimal stand-in for LanczosPrintUtils: the summary table in the reference's column
-    layout (printUtils.py:249-270) bracketed by its start/end markers, plus the final
-    eigenvalue block, so runs of the two codes can be diffed."""
+    """Stand-in for LanczosPrintUtils (printUtils.py:23-274): writes the SUMMARY file exactly in the
+    reference's layout - "startingPoint", the banner and parameter block of fileHeader (:59-166, also sent
+    to the iterations file), the column header, one row per cumulative iteration (:249-270),
+    "endingPoint" and the closing banner (:168-187) - so that runs of the two codes diff to nothing but
+    dates and wall-clock times (pinned by tests/test_host_logic.py against files the reference wrote).
+    The iterations file carries the header and the FINAL RESULTS block (:237-247); the per-iteration
+    matrix dumps are not reproduced (out of scope)."""
 
-    def __init__(self, enabled, sigma, L, maxit, eConv, eShift, out_name, sum_name, options):
+    _RULE = "*" * 70
+    _ITEM = "{:12} {:>14} :: {:20}"
+
+    def __init__(self, enabled, sigma, L, maxit, eConv, eShift, out_name, sum_name, options,
+                 nBlock=1, checkFitTol=1e-7, pick=None, phase=1):
         self.enabled = bool(enabled)
-        self.sigma, self.eShift = sigma, eShift
+        self.sigma, self.eShift, self.nBlock = sigma, eShift, nBlock
         self.out = self.sum = None
-        if self.enabled:
-            self.out = open(out_name or "iterations_lanczos.out", "w")
-            self.sum = open(sum_name or "summary_lanczos.out", "w")
-            self.out.write(f"inexact Lanczos: sigma={sigma} L={L} maxit={maxit} eConv={eConv}\n")
-            self.out.write(f"linearSystemArgs={options.get('linearSystemArgs')}\n")
-            self.sum.write("startingPoint\n")
-            self.sum.write("{:>4} {:>6} {:>6} {:>12}{:>18}{:>16} {:>16}\n".format(
-                "it", "i", "nCum", "target", "Evalue", "residual", "time"))
+        if not self.enabled:
+            return
+        self.out = open(out_name or "iterations_lanczos.out", "w")
+        self.sum = open(sum_name or "summary_lanczos.out", "w")
+        self.sum.write("startingPoint\n")
+        items = [("target", f"{sigma - eShift:.2f}", "target excitation"), ("L", L, "Krylov space"),
+                 ("maxit", maxit, "Maximum Lanczos iterations"), ("econv", f"{eConv:.03g}", "Eigenvalue convergence"),
+                 ("checkFitTol", checkFitTol, "Checkfit tolerance")]
+        head = self._banner("Starting computation") + "\n" + f"# Inexact Lanczos with {nBlock} guess vectors\n\n"
+        head += "".join(self._ITEM.format(*it) + "\n" for it in items)
+        head += "{:10} {:>20}".format("pick", str(pick).split(" ")[1] if pick is not None else "None") + "\n"
+        lsa = options.get("linearSystemArgs") if isinstance(options, dict) else None
+        if lsa is not None:                  # the reference echoes these for NumpyVector only (:102-112)
+            head += self._ITEM.format("lsweep", lsa["linearIter"], "Number of sweeps: Linear solver") + "\n"
+            head += self._ITEM.format("solver", lsa["linearSolver"], "Linear solver") + "\n"
+            head += self._ITEM.format("ltol", lsa["linear_tol"], "Tolerance: Linear solver") + "\n"
+        head += self._ITEM.format("Phase", phase, "Stage of phase calculation") + "\n\n"
+        self.out.write(head)
+        self.sum.write(head)
+        cols = "{:>4} {:>6} {:>6} {:>12}".format("it", "i", "nCum", "target")
+        cols += "".join("{:>18}".format(f"EvalueBlock{k + 1}") for k in range(nBlock))
+        self.sum.write(cols + "{:>16} {:>16}".format("residual", "time(seconds)\n"))
+        self.out.flush()
+        self.sum.flush()
+
+    @classmethod
+    def _banner(cls, text):
+        stamp = time.strftime("%d/%m/%Y %H:%M:%S")
+        return f"{cls._RULE}\n\t\t{text}\t\t\n\t\t{stamp}\t\t\n{cls._RULE}\n"
 
     def summary(self, block_ev, status):
         if not self.enabled:
             return
         line = "{:>4} {:>6} {:>6} {:>12}".format(status["outerIter"], status["innerIter"],
                                                  status["cumIter"], f"{self.sigma - self.eShift:5.2f}")
-        for e in block_ev:
-            line += "{:>18}".format(f"{e - self.eShift:.10f}")
+        for k in range(status["nBlock"]):
+            line += "{:>18}".format(f"{block_ev[k] - self.eShift:.10f}")
         line += "{:>16} {:>16}".format(f"{status['residual']:5.4e}", f"{status['runTime']:.2f}\n")
         self.sum.write(line)
         self.sum.flush()
@@ -86,12 +115,16 @@ class _SummaryWriter:
     def results(self, ev):
         if not self.enabled:
             return
-        self.out.write("\n\n" + "-" * 20 + "\tFINAL RESULTS\t" + "-" * 20 + "\n")
-        self.out.write("All subspace eigenvalues:\n" + f"{np.asarray(ev) - self.eShift}\n")
-        if ev is not None and len(ev) and not np.all(np.isnan(ev)):
-            self.out.write(f"Target, Lanczos (nearest) {self.sigma - self.eShift}, "
-                           f"{find_nearest(np.asarray(ev) - self.eShift, self.sigma - self.eShift)[1]}\n")
+        shifted = np.asarray(ev) - self.eShift
+        text = "\n\n" + "-" * 20 + "\tFINAL RESULTS\t" + "-" * 20 + "\n"
+        text += "All subspace eigenvalues:\n" + f"{shifted}\n"
+        target = self.sigma - self.eShift
+        text += f"Target, Lanczos (nearest) {target}, {find_nearest(shifted, target)[1]}\n"
+        self.out.write(text)
         self.sum.write("endingPoint\n")
+        foot = "\n" + self._banner("End of computation") + "\n\n"
+        self.out.write(foot)
+        self.sum.write(foot)
         self.out.close()
         self.sum.close()
 
@@ -143,10 +176,23 @@ class KrylovSpace:
         return len(self.Y)
 
 
-def _expand(Hsolve, vec, sigma, eConv):
+def _solve_newest_block(Hsolve, Y, nBlock, sigma):
+    """The nBlock solves of one iteration (:319-320) through the backend's optional ``solveBlock`` hook,
+    in the order the reference issues them (newest vector first), or None when the backend has no such
+    hook / the block is a single vector / ``options["blockSolve"]`` is False - then ``_expand`` solves
+    one by one exactly like the reference."""
+    cls = type(Y[0])
+    if nBlock < 2 or not hasattr(cls, "solveBlock"):
+        return None
+    if not getattr(Y[-1], "options", {}).get("blockSolve", True):
+        return None
+    return cls.solveBlock(Hsolve, [Y[-back] for back in range(1, nBlock + 1)], sigma)
+
+
+def _expand(Hsolve, vec, sigma, eConv, solved=None):
     """One shift-and-invert step (generateSubspace, inexact_Lanczos.py:84-105)."""
     cls = type(vec)
-    w = cls.solve(Hsolve, vec, sigma)
+    w = cls.solve(Hsolve, vec, sigma) if solved is None else solved
     if cls.norm(w) > 0.001 * eConv:
         return cls.normalize(w), True
     return w, False
@@ -251,7 +297,8 @@ def inexactLanczosDiagonalization(H, v0: Union[AbstractVector, List[AbstractVect
         pick = get_pick_function_close_to_sigma(sigma)
     assert callable(pick)
     writer = _SummaryWriter(writeOut, sigma, L, maxit, eConv, eShift, outFileName, summaryFileName,
-                            space.Y[0].options if hasattr(space.Y[0], "options") else {})
+                            space.Y[0].options if hasattr(space.Y[0], "options") else {},
+                            nBlock=nBlock, checkFitTol=checkFitTol, pick=pick, phase=status["phase"])
 
     ev, T = None, None
     lindep_problem = False
@@ -277,8 +324,9 @@ def inexactLanczosDiagonalization(H, v0: Union[AbstractVector, List[AbstractVect
             status["cumIter"] += 1
             # (A) nBlock shift-and-invert solves on the newest block (:319-327)
             fresh = []
+            solved = _solve_newest_block(Hsolve, space.Y, nBlock, sigma)
             for back in range(1, nBlock + 1):
-                w, nonzero = _expand(Hsolve, space.Y[-back], sigma, eConv)
+                w, nonzero = _expand(Hsolve, space.Y[-back], sigma, eConv, None if solved is None else solved[back - 1])
                 if not nonzero:
                     status["zeroVector"] = True
                     warnings.warn(f"Alert: zero vector: ||inv(H-sigma)vec||={cls.norm(w):5.3e}")

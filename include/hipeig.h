@@ -43,8 +43,10 @@ const char* hipeig_last_error(void);
 int hipeig_device_info(hipeig_ctx* ctx, int64_t info[8], char* name, int name_len);
 
 /* ---- communicator (one process per GPU; RCCL over xGMI) --------------------------- */
-/* The host side exchanges the 128-byte id out of band (torch.distributed/gloo, MPI...). */
+/* The host side exchanges the 128-byte id out of band (eigensolvers_amd.distributed: a TCP exchange). */
 int hipeig_comm_unique_id(void* id128);
+/* path of the RCCL library in use (ROCm's /opt/rocm/lib/librccl.so unless HIPEIG_RCCL_LIB says otherwise) */
+int hipeig_comm_library(char* path, int path_len);
 int hipeig_comm_init(hipeig_ctx* ctx, int nranks, int rank, const void* id128);
 int hipeig_comm_destroy(hipeig_ctx* ctx);
 int hipeig_comm_info(hipeig_ctx* ctx, int* nranks, int* rank);
@@ -168,6 +170,12 @@ int hipeig_spmv_shift(hipeig_ctx* ctx, hipeig_csr* A, double sigma, double sign,
  * Y[j] = H X[j], j < k.  Internally the operands are interleaved so that each non-zero costs
  * one index fetch and one contiguous gather for all k (tall-skinny SpMM).                   */
 int hipeig_spmm(hipeig_ctx* ctx, hipeig_csr* A, int k, const double* const* X, double* const* Y);
+/* Kernel choice of the block product / block solve: 0 = automatic, 1 = row-owner CSR (a wavefront per row,
+ * 64-byte gathers from wherever the operand block lives), 2 = column-window blocked (operand windows
+ * L2-resident, 8 accumulators per row in LDS).  info[0] = variant of the last block launch, [1] = row
+ * blocks, [2] = column windows, [3] = rows per row block of the window-blocked layout.              */
+int hipeig_csr_set_block_variant(hipeig_csr* A, int variant);
+int hipeig_csr_block_info(hipeig_csr* A, int64_t info[4]);
 
 /* ---- inner linear solve: NumpyVector.solve with linearSolver="minres" (:147-178) ---- */
 /* Solves sign*(sigma*I - H) x = b from a zero initial guess with the Paige-Saunders
@@ -178,6 +186,15 @@ int hipeig_spmm(hipeig_ctx* ctx, hipeig_csr* A, int k, const double* const* X, d
  * *info follows SciPy: maxiter if the iteration limit was hit (istop==6) else 0.         */
 int hipeig_minres(hipeig_ctx* ctx, hipeig_csr* A, double sigma, double sign, const double* b,
                   double* x, double rtol, int maxiter, int* info, double out_stats[8]);
+
+/* The nBlock solves of one block-Lanczos iteration (inexact_Lanczos.py:319-320: one NumpyVector.solve
+ * per block vector, same operator, same shift) advanced in lock step: k <= 8 right-hand sides, ONE block
+ * product per iteration.  Column j runs exactly the recurrences and stopping tests of hipeig_minres on
+ * b[j]; a column that has stopped is masked, so x[j] is the iterate SciPy would return for it.
+ * info[j] as in hipeig_minres; out_stats (may be NULL) receives k records of 8 doubles.             */
+int hipeig_minres_block(hipeig_ctx* ctx, hipeig_csr* A, double sigma, double sign, int k,
+                        const double* const* b, double* const* x, double rtol, int maxiter,
+                        int* info, double* out_stats);
 
 /* ---- timing on the library's compute stream (HIP events) --------------------------- */
 int hipeig_timer_start(hipeig_ctx* ctx);

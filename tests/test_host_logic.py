@@ -9,7 +9,7 @@ import pytest
 import scipy.linalg as la
 
 import eigensolvers_amd as ea
-from conftest import load_golden
+from conftest import GOLDEN, load_golden
 from eigensolvers_amd import subspace
 from eigensolvers_amd.distributed import all_row_ranges, row_range
 from eigensolvers_amd.generators import dense_test_matrix, gapped_csr_host, gapped_params
@@ -86,16 +86,54 @@ def test_driver_argument_errors_and_guess_normalisation():
                                          writeOut=False)
 
 
-def test_summary_file_layout(tmp_path, gapped4000):
+def _summary_rows(text):
+    """(frame lines, table rows) of a summary file: dates and the wall-clock column masked."""
+    frame, rows = [], []
+    for line in text.splitlines():
+        cells = line.split()
+        if cells and cells[0].isdigit() and len(cells) >= 7:
+            rows.append(cells[:-1])                         # drop time(seconds)
+        elif "/" in line and ":" in line and line.startswith("\t\t"):
+            frame.append("<date>")
+        else:
+            frame.append(line)
+    return frame, rows
+
+
+@pytest.mark.parametrize("case", ["single", "block8"])
+def test_summary_file_equals_the_references(tmp_path, gapped4000, case):
+    """f3: the summary file against the one the reference's LanczosPrintUtils wrote for the same run
+    (printUtils.py:59-187, 249-270; tests/golden/summary_lanczos_*.out from make_golden_r2.py): same
+    frame, same column layout, same iteration counters, same printed eigenvalues and residuals."""
     H, guess = gapped4000
     out, summ = tmp_path / "it.out", tmp_path / "sum.out"
-    ea.inexactLanczosDiagonalization(H, RefVector(guess.copy(), _opts("minres", 2000, 1e-6)), 0.02, 3, 1, 1e-6,
-                                     writeOut=True, outFileName=str(out), summaryFileName=str(summ))
-    lines = summ.read_text().splitlines()
-    assert lines[0] == "startingPoint" and lines[-1] == "endingPoint"
-    cols = lines[2].split()
-    assert cols[:3] == ["0", "1", "1"] and len(cols) == 7  # it, i, nCum, target, Evalue, residual, time
-    assert "FINAL RESULTS" in out.read_text()
+    if case == "single":
+        v0 = RefVector(guess.copy(), {"linearSystemArgs": {"linearSolver": "minres", "linearIter": 2000,
+                                                           "linear_tol": 1e-10, "linear_atol": 1e-12}})
+        args, kw = (0.02, 8, 10, 1e-13), dict(eShift=0.005)
+    else:
+        g = load_golden("gapped_csr_n4000_block8.npz")
+        Q = la.qr(np.random.default_rng(5).standard_normal((4000, 8)), mode="economic")[0]
+        v0 = [RefVector(Q[:, i].copy(), _opts("minres", 2000, float(g["linear_tol"]))) for i in range(8)]
+        args, kw = (0.02, int(g["L"]), int(g["maxit"]), float(g["eConv"])), {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ev, Y, st = ea.inexactLanczosDiagonalization(H, v0, *args, writeOut=True, outFileName=str(out),
+                                                     summaryFileName=str(summ), **kw)
+    ref_text = open(os.path.join(GOLDEN, f"summary_lanczos_{case}.out")).read()
+    frame, rows = _summary_rows(summ.read_text())
+    rframe, rrows = _summary_rows(ref_text)
+    assert frame == rframe                                   # banner, parameter block, column header, markers
+    assert frame[0] == "startingPoint" and "endingPoint" in frame
+    assert len(rows) == len(rrows) == st["cumIter"]
+    for r, rr in zip(rows, rrows):
+        assert r[:4] == rr[:4]                               # it, i, nCum, target
+        if r != rr:                                          # another BLAS: the printed digits may move
+            np.testing.assert_allclose([float(c) for c in r[4:-1]], [float(c) for c in rr[4:-1]], rtol=0, atol=5e-6)
+    if case == "single":
+        tail = out.read_text().split("FINAL RESULTS")[-1].split("*" * 70)[0]
+        rtail = open(os.path.join(GOLDEN, "iterations_lanczos_single_tail.out")).read().split("*" * 70)[0]
+        assert tail.split() == rtail.split()                 # eigenvalue block and the "Target, Lanczos (nearest)" line
 
 
 def test_subspace_helpers_against_reference_outputs(gapped4000):

@@ -1,0 +1,111 @@
+"""Drop-in boundary conformance, asserted against data: ``tests/golden/surface.json``
+is the ``inspect.signature`` dump of the reference's own ``AbstractVector`` / ``NumpyVector``
+(abstractVector.py:15-169, numpyVector.py:23-238) and of its two solver entry points, written by
+``tests/golden/make_golden_r2.py`` from the imported reference.  No GPU needed: only signatures."""
+import inspect
+import json
+import os
+
+import pytest
+
+import eigensolvers_amd as ea
+from eigensolvers_amd import abstract_vector as av
+from eigensolvers_amd.hip_vector import HipVector
+from conftest import GOLDEN
+
+SURFACE = json.load(open(os.path.join(GOLDEN, "surface.json")))
+
+
+def _params(fn):
+    return [[p.name, p.kind.name, None if p.default is inspect._empty else repr(p.default)]
+            for p in inspect.signature(fn).parameters.values()]
+
+
+def _member(cls, name):
+    obj = inspect.getattr_static(cls, name)
+    if isinstance(obj, staticmethod):
+        return "staticmethod", obj.__func__
+    if isinstance(obj, property):
+        return "property", obj.fget
+    return "method", obj
+
+
+def test_abstract_vector_equals_the_reference_abc():
+    ref = SURFACE["AbstractVector"]
+    assert av.LINDEP_DEFAULT_VALUE == SURFACE["LINDEP_DEFAULT_VALUE"]
+    assert sorted(av.AbstractVector.__abstractmethods__) == SURFACE["abstractmethods"]
+    for name, spec in ref.items():
+        kind, fn = _member(av.AbstractVector, name)
+        assert kind == spec["kind"], name
+        assert _params(fn) == spec["params"], name
+        assert bool(getattr(fn, "__isabstractmethod__", False)) == spec["abstract"], name
+    ours = {n for n in vars(av.AbstractVector) if not n.startswith("_") or n in ref}
+    assert ours == set(ref), ours ^ set(ref)                    # nothing added, nothing missing
+    assert set(av.PROPERTIES) | set(av.METHODS) | set(av.STATIC_HOOKS) == set(ref)
+    for name in av.STATIC_HOOKS:                                # the reference's defaults raise
+        with pytest.raises(NotImplementedError):
+            getattr(av.AbstractVector, name)(*([None] * sum(p[2] is None for p in ref[name]["params"])))
+
+
+def test_hip_vector_has_numpy_vectors_signatures():
+    ref = SURFACE["NumpyVector"]
+    assert issubclass(HipVector, av.AbstractVector) and not HipVector.__abstractmethods__
+    for name, spec in ref.items():
+        kind, fn = _member(HipVector, name)
+        got = _params(fn)
+        if name == "__init__":
+            # same leading parameters (array, options); ours adds an optional context and spells the
+            # empty default None instead of a shared mutable {}
+            assert [p[0] for p in got[:3]] == [p[0] for p in spec["params"]]
+            assert all(p[2] is not None for p in got[2:])
+            continue
+        if spec["kind"] == "property":
+            assert kind == "property", name
+            continue
+        # the reference declares its hooks as plain functions in the class body and calls them unbound
+        # (typeClass.f(...)); a staticmethod is callable the same way
+        assert got == spec["params"], f"{name}: {got} != {spec['params']}"
+    extra = {n for n in vars(HipVector) if not n.startswith("_")} - set(ref)
+    assert extra <= {"fromArray", "array", "linearCombinationBlock", "solveBlock"}, extra
+
+
+def test_solver_entry_points_accept_the_reference_arguments():
+    for ours, key in ((ea.inexactLanczosDiagonalization, "inexactLanczosDiagonalization"),
+                      (ea.feastDiagonalization, "feastDiagonalization")):
+        got, ref = _params(ours), SURFACE[key]
+        assert [p[:2] for p in got[:len(ref)]] == [p[:2] for p in ref]             # same names, same order
+        for g, r in zip(got, ref):
+            if r[0] == "saveTNSsEachIteration":
+                assert g[2] == "False" and r[2] == "True"       # documented deviation: HEAD's default crashes
+            else:
+                assert g[2] == r[2], r[0]
+        assert all(p[2] is not None for p in got[len(ref):])    # additions are optional
+
+
+def test_integration_stub_is_a_concrete_backend_of_the_reference_abc():
+    """``class HipVector(_hv.HipVector, AbstractVector)`` in the reference tree.
+    The reference's ABC is rebuilt here from surface.json (same abstract members, same static hooks);
+    the stub must leave no abstract member open and must keep HipVector's implementations in front."""
+    import abc
+    ref = SURFACE["AbstractVector"]
+    body = {}
+    for name, spec in ref.items():
+        def make(nm):
+            def f(*a, **k):
+                raise NotImplementedError(nm)
+            f.__name__ = nm
+            return f
+        fn = make(name)
+        if spec["abstract"]:
+            fn = abc.abstractmethod(fn)
+        body[name] = property(fn) if spec["kind"] == "property" else staticmethod(fn) if spec["kind"] == "staticmethod" else fn
+    RefABC = abc.ABCMeta("AbstractVector", (), body)
+    assert sorted(RefABC.__abstractmethods__) == SURFACE["abstractmethods"]
+
+    class Stub(HipVector, RefABC):
+        pass
+
+    assert not Stub.__abstractmethods__
+    for name in ref:
+        assert inspect.getattr_static(Stub, name) is inspect.getattr_static(HipVector, name), name
+    assert issubclass(Stub, RefABC) and issubclass(Stub, av.AbstractVector)
