@@ -11,7 +11,10 @@ on the same operator.
 One process per GPU.  With N > 1 the SAME N = 1e7 operator is row-partitioned over the ranks
 (strong scaling: total work fixed); every step is an RCCL all-gather of the operand slice
 followed by the local CSR sweep.  A "step" is one operator application.  Inputs are
-generated on the device and are resident in HBM before the timed region.
+generated on the device and are resident in HBM before the timed region.  No torch anywhere:
+the launcher's RANK / WORLD_SIZE / MASTER_* variables are read directly, RCCL's unique id
+travels over a stdlib TCP exchange and barriers / max-over-ranks use the library's own
+all-reduce (eigensolvers_amd.distributed).
 
 Rank 0 prints ONE JSON line; `value` is whole-job algorithmic GB/s (SURVEY.md section 8d
 bytes of the GLOBAL operator x steps / max-over-ranks wall time); `roofline` prices the
@@ -28,7 +31,8 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0   # same guide: measured float4 copy (79 % of spec)
 
 
 def parse():
@@ -46,6 +50,7 @@ def parse():
     ap.add_argument("--lanczos-L", type=int, default=8)
     ap.add_argument("--lanczos-maxit", type=int, default=4)
     ap.add_argument("--lanczos-econv", type=float, default=1e-10)
+    ap.add_argument("--cpu-lanczos-n", type=int, default=100_000, help="size of the CPU Lanczos baseline instance (~15 s of one core)")
     return ap.parse_args()
 
 
@@ -55,6 +60,7 @@ def global_bytes(N, nnz):
 
 def main(result):
     a = parse()
+    import ctypes as C
     import numpy as np
     import eigensolvers_amd as ea
     from eigensolvers_amd import distributed as D
@@ -62,38 +68,20 @@ def main(result):
     rank, world, local_rank = D.world_from_env()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    dist = None
     force = os.environ.get("HIPEIG_FORCE_COLLECTIVES", "0") not in ("", "0")     # rehearse the RCCL path on one rank
-    if world > 1 or force:
-        dist = D.init_process_group_gloo()
     try:
         ctx = ea.HipContext(local_rank)
     except ea._lib.HipEigError:                      # launcher already narrowed the visible devices to one
         ctx = ea.HipContext(0)
     ea.HipContext._default = ctx
+    rccl_lib = None
     if world > 1 or force:
-        D.attach_rccl(ctx)
-
-    def barrier():
-        ctx.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    def allmax(x):
-        if dist is None:
-            return x
-        import torch
-        t = torch.tensor([x], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t[0])
-
-    def allsum(x):
-        if dist is None:
-            return x
-        import torch
-        t = torch.tensor([x], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return float(t[0])
+        D.attach_rccl(ctx, rank, world)
+        buf = C.create_string_buffer(512)
+        ea._lib.call("hipeig_comm_library", buf, 512)
+        rccl_lib = buf.value.decode()
+    group = D.DeviceGroup(ctx)
+    barrier, allmax, allsum = group.barrier, group.allmax, group.allsum
 
     N = a.n
     b, e = D.row_range(N, world, rank)
@@ -143,10 +131,12 @@ def main(result):
                                f"row-partitioned over {world} GPU(s)",
                    "N": N, "nnz": nnz_total, "nnz_per_row": round(nnz_total / N, 3), "sigma": a.sigma,
                    "kernel_variant": ("auto:" if a.variant == 0 else "forced:") + H.last_variant(),
-                   "generator_seed": a.seed, "generate_s": round(t_gen, 2)},
+                   "generator_seed": a.seed, "generate_s": round(t_gen, 2), "rccl_library": rccl_lib},
         "roofline": {"bound": "hbm", "kernel": kname,
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4), "achievable_peak": HBM_ACHIEVABLE_GBS,
+                     "traffic": traffic,
                      "traffic_source": "profiles/pmc_current.json (separate rocprofv3 --pmc passes)" if traffic else None,
                      "launches_per_step": nlaunch,
                      "algorithmic_bytes_per_launch": int(H.algorithmic_bytes() // nlaunch),
@@ -194,7 +184,23 @@ def main(result):
             blas = [(d.get("internal_api"), d.get("num_threads")) for d in threadpoolctl.threadpool_info()]
         except Exception:
             blas = None
+        # (ii) Lanczos iterations/s of the CPU restatement of the reference path (oracle/: NumPy + SciPy MINRES,
+        # numpyVector.py:147-178 under inexact_Lanczos.py:229-443) on a bounded instance of the same generator
+        from oracle import lanczos_ref
+        from oracle.numpy_vector import RefVector
+        from eigensolvers_amd.generators import gapped_csr_host, guess_vector
+        n_cpu = min(N, a.cpu_lanczos_n)
+        Hc = gapped_csr_host(n_cpu, a.nnz_row, seed=a.seed)
+        tl0 = time.perf_counter()
+        evc, Yc, stc = lanczos_ref.inexact_lanczos(Hc, RefVector(guess_vector(n_cpu, 1).copy(), {"linearSystemArgs": {
+            "linearSolver": "minres", "linearIter": 2000, "linear_tol": 1e-10}}), a.sigma, 3, 1, a.lanczos_econv)
+        tl0 = time.perf_counter() - tl0
+        cpu_lanczos = {"N": n_cpu, "nnz_per_row": round(Hc.nnz / n_cpu, 2), "cum_iters": int(stc["cumIter"]),
+                       "seconds": round(tl0, 2), "iters_per_s": round(stc["cumIter"] / tl0, 4), "ritz_value": float(evc[0]),
+                       "what": "oracle.lanczos_ref (NumPy/SciPy restatement of the reference path), one cycle L=3, "
+                               "minres rtol 1e-10, single-threaded csr_matvec"}
         out["cpu_baseline"] = {"value": round(sb * reps / tc, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+                               "lanczos": cpu_lanczos,
                                "sample": f"rows [0,{rows}) of the same operator ({slab.nnz} nnz), x of full length {N}, "
                                          f"{reps} reps of sigma*x - H@x via scipy.sparse csr_matvec (single-threaded), "
                                          f"{tc:.1f} s",
@@ -202,9 +208,7 @@ def main(result):
                                "numpy": np.__version__, "scipy": __import__("scipy").__version__}
     if rank == 0:
         result["line"] = json.dumps(out)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    barrier()
 
 
 if __name__ == "__main__":

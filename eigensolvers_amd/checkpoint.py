@@ -11,6 +11,10 @@ reader: one ``.npz`` per cumulative iteration holding
 * ``status``              - the status dictionary as JSON (arrays as lists),
 * ``meta``                - JSON: sigma, L, eConv, nBlock, partition (rank, nranks), format version.
 
+Resuming reproduces the uninterrupted run bit for bit where the backend's arithmetic is reproducible
+(ndarray backends; HipVector with operator kernel variants 1-3 - the default variant 4 for large
+operators sums a row with LDS atomics and agrees to rounding only).
+
 Files are written to a temporary name and renamed, so a run killed while writing leaves the previous
 checkpoint intact; by default only the newest ``keep`` checkpoints are retained.  Nothing here
 touches the device: vectors are read through ``.array`` and rebuilt through the backend's
@@ -28,7 +32,7 @@ import numpy as np
 FORMAT_VERSION = 1
 
 __all__ = ["save_checkpoint", "load_checkpoint", "latest_checkpoint", "restore_vectors",
-           "checkpoint_name"]
+           "checkpoint_name", "check_meta"]
 
 
 def _partition_of(vec):
@@ -100,15 +104,36 @@ def load_checkpoint(path):
     return out
 
 
-def latest_checkpoint(saveDir, rank=0, nranks=1):
-    """Newest checkpoint of this rank in ``saveDir`` (None when there is none)."""
+def _iterations_of(saveDir, rank, nranks):
     tag = "" if nranks == 1 else f".r{rank}of{nranks}"
-    best, best_it = None, -1
+    its = set()
     for f in glob.glob(os.path.join(saveDir, f"krylov_*{tag}.npz")):
         m = re.fullmatch(rf"krylov_(\d+){re.escape(tag)}\.npz", os.path.basename(f))
-        if m and int(m.group(1)) > best_it:
-            best, best_it = f, int(m.group(1))
-    return best
+        if m:
+            its.add(int(m.group(1)))
+    return its
+
+
+def latest_checkpoint(saveDir, rank=0, nranks=1):
+    """This rank's file of the newest iteration that is COMPLETE, i.e. for which every rank of the
+    partition has a file (None when there is none).  Ranks write and prune independently, so after a
+    crash between two ranks' writes their newest files can belong to different iterations; resuming each
+    rank from its own newest file would make the ranks issue different numbers of collectives.  All
+    ranks see the same directory and therefore pick the same iteration."""
+    common = _iterations_of(saveDir, 0, nranks)
+    for r in range(1, nranks):
+        common &= _iterations_of(saveDir, r, nranks)
+    if not common:
+        return None
+    return checkpoint_name(saveDir, max(common), rank, nranks)
+
+
+def check_meta(meta, sigma, L, eConv, nranks, path="checkpoint"):
+    """Refuse to continue a run whose parameters differ from the ones the checkpoint was written with."""
+    for key, now in (("sigma", sigma), ("L", L), ("eConv", eConv), ("nranks", nranks)):
+        was = meta.get(key)
+        if was is not None and now is not None and was != now:
+            raise ValueError(f"{path}: written with {key}={was!r}, resumed with {key}={now!r}")
 
 
 def restore_vectors(template, basis):

@@ -3,7 +3,10 @@
 // Every kernel is a grid-stride sweep with 16-byte (double2) accesses, at most
 // HIPEIG_MAX_PARTIALS workgroups of 256 threads.  Reductions are two-stage with a fixed
 // tree (wave shuffle -> LDS -> per-workgroup partial -> fixed-order final sum), never
-// atomics, so results are bitwise reproducible.
+// atomics, so the results of THESE kernels are bitwise reproducible.  (The operator sweeps are a
+// separate matter: kernel variants 1-3 of spmv_device.h fix the order of the adds inside a row, the
+// default variant 4 for large operators and the block kernel of spmm_device.h accumulate with LDS
+// atomics and reproduce a row's sum only to rounding.)
 #include "common.h"
 #include <math.h>
 #include <vector>
@@ -280,17 +283,29 @@ extern "C" int hipeig_lincomb_block(hipeig_ctx* c, int64_t n, int m, int k, cons
   for (int j = 0; j < m; ++j)
     for (int q = 0; q < k; ++q) HIPEIG_REQUIRE(vecs[j] != outs[q], "an output must not alias an input");
   if (n == 0) return 0;
-  // pageable sources: the runtime has staged them when hipMemcpyAsync returns
-  HIPEIG_CHECK(hipMemcpyAsync((void*)c->d_ptrs, vecs, sizeof(double*) * m, hipMemcpyHostToDevice, c->stream));
+  // Sources of asynchronous copies are the context's PINNED staging buffers (h_ptrs, h_scalars), never
+  // pageable memory that goes out of scope or is refilled while a copy may still be reading it; the
+  // buffers are reused by later calls, so the stream is drained once before they are rewritten.
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  for (int j = 0; j < m; ++j) c->h_ptrs[j] = vecs[j];
+  HIPEIG_CHECK(hipMemcpyAsync((void*)c->d_ptrs, c->h_ptrs, sizeof(double*) * m, hipMemcpyHostToDevice, c->stream));
   const int g = grid_for(n, 2);
   double* dcoef = c->d_partials;                      // free here: this call has no reduction
-  std::vector<double> cf((size_t)m * HIPEIG_MAX_COLS);
+  double* cf = c->h_scalars;
+  size_t cf_used = 0;
   for (int c0 = 0; c0 < k; c0 += HIPEIG_MAX_COLS) {
     const int kk = (k - c0 < HIPEIG_MAX_COLS) ? (k - c0) : HIPEIG_MAX_COLS;
     const int KB = kk <= 4 ? 4 : kk <= 8 ? 8 : HIPEIG_MAX_COLS;
+    if (cf_used + (size_t)m * KB > c->scalars_doubles) {            // staging area full: wait for the copies issued so far
+      HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+      cf_used = 0;
+    }
+    HIPEIG_REQUIRE((size_t)m * KB <= c->scalars_doubles, "too many input vectors for the coefficient staging buffer");
+    double* slot = cf + cf_used;
     for (int j = 0; j < m; ++j)
-      for (int q = 0; q < KB; ++q) cf[(size_t)j * KB + q] = (q < kk) ? C[(size_t)j * ldc + c0 + q] : 0.0;
-    HIPEIG_CHECK(hipMemcpyAsync(dcoef, cf.data(), sizeof(double) * m * KB, hipMemcpyHostToDevice, c->stream));
+      for (int q = 0; q < KB; ++q) slot[(size_t)j * KB + q] = (q < kk) ? C[(size_t)j * ldc + c0 + q] : 0.0;
+    HIPEIG_CHECK(hipMemcpyAsync(dcoef, slot, sizeof(double) * m * KB, hipMemcpyHostToDevice, c->stream));
+    cf_used += (size_t)m * KB;
     OutTable ot;
     for (int q = 0; q < HIPEIG_MAX_COLS; ++q) ot.p[q] = (q < kk) ? outs[c0 + q] : nullptr;
     if (KB == 4)
@@ -302,6 +317,7 @@ extern "C" int hipeig_lincomb_block(hipeig_ctx* c, int64_t n, int m, int k, cons
     HIPEIG_CHECK(hipGetLastError());
     dcoef += (size_t)m * KB;
   }
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));       // the staging buffers are free for the next call
   return 0;
 }
 

@@ -290,7 +290,10 @@ int hipeig_comm_setup_rows(hipeig_ctx* c, int64_t nrows_local, int64_t* stride_o
     return 0;
   }
   int64_t* d = (int64_t*)c->d_scalars;
-  HIPEIG_CHECK(hipMemcpyAsync(d + c->rank, &nrows_local, sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));            // the pinned staging word below is free
+  int64_t* staged = (int64_t*)c->h_scalars;
+  staged[0] = nrows_local;
+  HIPEIG_CHECK(hipMemcpyAsync(d + c->rank, staged, sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
   if (coll_allgather(c, d + c->rank, d, 1, NCCL_INT64, c->stream)) return 4;
   HIPEIG_CHECK(hipMemcpyAsync(c->row_counts, d, sizeof(int64_t) * c->nranks, hipMemcpyDeviceToHost, c->stream));
   HIPEIG_CHECK(hipStreamSynchronize(c->stream));

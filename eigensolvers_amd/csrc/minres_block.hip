@@ -166,9 +166,12 @@ minres_block_kd_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ 
   if (live0 || live1) {
     for (int64_t t = t0; t < n * 4; t += stride) {
       const double2 rv = r2[t], b1 = w12[t], b2 = w22[t];
-      double2 xv = x2[t], wn = wn2[t];
-      if (live0) { wn.x = (s0 * rv.x - e0 * b1.x - d0 * b2.x) * q0; xv.x += p0 * wn.x; }
-      if (live1) { wn.y = (s1 * rv.y - e1 * b1.y - d1 * b2.y) * q1; xv.y += p1 * wn.y; }
+      double2 xv = x2[t], wn;
+      // a stopped column keeps its iterate; its w is never read again, so what is stored there is irrelevant
+      wn.x = (s0 * rv.x - e0 * b1.x - d0 * b2.x) * q0;
+      wn.y = (s1 * rv.y - e1 * b1.y - d1 * b2.y) * q1;
+      if (live0) xv.x += p0 * wn.x;
+      if (live1) xv.y += p1 * wn.y;
       wn2[t] = wn;
       x2[t] = xv;
       a0 = fma(xv.x, xv.x, a0); a1 = fma(xv.y, xv.y, a1);

@@ -122,7 +122,7 @@ int hipeig_block_pick_variant(hipeig_ctx* c, hipeig_csr* A) {
   if (A->block_variant == 1 || A->nnz == 0 || A->nrows == 0) return A->last_block_variant = 1;
   if (A->b_state == 1) return A->last_block_variant = 2;
   if (A->b_state == 2 && A->block_variant == 0) return A->last_block_variant = 1;
-  int wbits = 13;                                        // 8 Ki columns x 64 B = 512 KiB of X per window (measured best of 12..16 at N = 1e6)
+  int wbits = 11;                                        // 2 Ki columns x 64 B = 128 KiB of X per window (measured best of 8..15 at N = 1e6: 32 windows fit one L2, so workgroups that drift apart still hit)
   if (const char* e = getenv("HIPEIG_BCOO_WBITS")) wbits = atoi(e);          // tuning knob
   if (wbits < 8 || wbits > 20) { hipeig_set_error("HIPEIG_BCOO_WBITS out of range"); return -1; }
   while (wbits > 8 && ((int64_t)1 << (wbits - 1)) >= A->gather_len) --wbits;

@@ -28,6 +28,9 @@
 
 #define BCOO_K 8                          // interleave width (operands per block, zero padded)
 #define BCOO_THREADS 1024
+#ifndef BCOO_NB
+#define BCOO_NB 2                         // sub-batches of 64 non-zeros per wave step: 4 * BCOO_NB gathers in flight per wave
+#endif
 #define BCOO_MAX_RW 2520                  // 161,280 B of accumulators (+ the unit's window offsets)
 #define BCOO_MAX_WIN 4096                 // (nwin + 2) offsets share the dynamic LDS with the accumulators
 #define HIPEIG_BCOO_LDS_MAX ((size_t)161792)     // dynamic LDS; 2 KiB of the CU's 160 KiB stay for the kernels' static arrays
@@ -71,41 +74,44 @@ __device__ __forceinline__ void bcoo_wg_sweep(const BcooView& T, const double* _
   for (int k = threadIdx.x; k <= T.nwin; k += blockDim.x) offL[k] = T.off[(size_t)u * T.nwin + k];
   __syncthreads();
   const uint32_t sbeg = offL[0], send = offL[T.nwin];
-  const uint32_t step = (uint32_t)nw * 64;
+  // A wave takes BCOO_NB * 64 consecutive non-zeros per step (one (idx, val) pair per lane and sub-batch);
+  // the next step's stream loads are issued before this step's 4 * BCOO_NB gather instructions, which
+  // are all issued before the first of them is waited for.
+  const uint32_t step = (uint32_t)nw * 64 * BCOO_NB;
   const double2* __restrict__ X2 = reinterpret_cast<const double2*>(X);
   int c = 0;
-  uint32_t idA, idB;
-  double vA, vB;
+  uint32_t idA[BCOO_NB], idB[BCOO_NB];
+  double vA[BCOO_NB], vB[BCOO_NB];
   // Every load is unconditional (clamped index / column 0 for padding lanes) so that the compiler can
-  // keep the next batch's stream loads AND the four gathers of this batch in flight behind counted
-  // s_waitcnt vmcnt(N); with the loads inside exec-masked blocks it drained the queue (vmcnt(0)) after
-  // every single gather: one gather instruction in flight per wave, 0.57 ms per block iteration at
-  // N = 1e6 against 0.39 ms in this form.
+  // keep the stream loads and all gathers of a step in flight behind counted s_waitcnt vmcnt(N); with
+  // the loads inside exec-masked blocks it drained the queue (vmcnt(0)) after every single gather.
 #define BCOO_LOAD(ID, V, BASE)                                             \
-  {                                                                        \
-    const uint32_t q = (BASE) + lane;                                      \
+  _Pragma("unroll") for (int b = 0; b < BCOO_NB; ++b) {                    \
+    const uint32_t q = (BASE) + 64 * b + lane;                             \
     const uint32_t qc = q < send ? q : send - 1;                           \
-    ID = __builtin_nontemporal_load(T.idx + qc);                           \
-    V = __builtin_nontemporal_load(T.val + qc);                            \
+    ID[b] = __builtin_nontemporal_load(T.idx + qc);                        \
+    V[b] = __builtin_nontemporal_load(T.val + qc);                         \
   }
 #define BCOO_CONSUME(ID, V, BASE)                                          \
   {                                                                        \
-    const uint32_t q = (BASE) + lane;                                      \
-    while (c + 1 < T.nwin && q >= offL[c + 1]) ++c;                        \
-    const bool live = q < send;              /* padding lanes re-read the last element: masked here */ \
-    const uint32_t col = live ? ((uint32_t)c << T.wbits) + (ID & cmask) : 0u; \
-    const uint32_t row = live ? (ID >> T.wbits) : 0xFFFFFFFFu;             \
-    uint32_t row_t[4];                                                     \
-    double v_t[4];                                                         \
-    double2 g[4];                                                          \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                        \
-      const int src = t * 16 + quad;                                       \
-      const uint32_t col_t = bperm_u32(src, col);                          \
-      row_t[t] = bperm_u32(src, row);                                      \
-      v_t[t] = bperm_f64(src, V);                                          \
-      g[t] = X2[(size_t)col_t * (BCOO_K / 2) + sub];                       \
+    uint32_t row_t[4 * BCOO_NB];                                           \
+    double v_t[4 * BCOO_NB];                                               \
+    double2 g[4 * BCOO_NB];                                                \
+    _Pragma("unroll") for (int b = 0; b < BCOO_NB; ++b) {                  \
+      const uint32_t q = (BASE) + 64 * b + lane;                           \
+      while (c + 1 < T.nwin && q >= offL[c + 1]) ++c;                      \
+      const bool live = q < send;            /* padding lanes re-read the last element: masked here */ \
+      const uint32_t col = live ? ((uint32_t)c << T.wbits) + (ID[b] & cmask) : 0u; \
+      const uint32_t row = live ? (ID[b] >> T.wbits) : 0xFFFFFFFFu;        \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t) {                      \
+        const int src = t * 16 + quad;                                     \
+        const uint32_t col_t = bperm_u32(src, col);                        \
+        row_t[4 * b + t] = bperm_u32(src, row);                            \
+        v_t[4 * b + t] = bperm_f64(src, V[b]);                             \
+        g[4 * b + t] = X2[(size_t)col_t * (BCOO_K / 2) + sub];             \
+      }                                                                    \
     }                                                                      \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                        \
+    _Pragma("unroll") for (int t = 0; t < 4 * BCOO_NB; ++t) {              \
       if (row_t[t] != 0xFFFFFFFFu) {                                       \
         double* a = yacc + (size_t)row_t[t] * BCOO_K + sub * 2;            \
         lds_add_f64_blk(a, v_t[t] * g[t].x);                               \
@@ -113,8 +119,8 @@ __device__ __forceinline__ void bcoo_wg_sweep(const BcooView& T, const double* _
       }                                                                    \
     }                                                                      \
   }
-  uint32_t base = sbeg + (uint32_t)wid * 64;
-  if (base < send) {                                 // uniform per wave (send > sbeg: the clamp below is in range)
+  uint32_t base = sbeg + (uint32_t)wid * 64 * BCOO_NB;
+  if (base < send) {                                 // uniform per wave (send > sbeg: the clamp above is in range)
     BCOO_LOAD(idA, vA, base)
     while (true) {
       const uint32_t nb = base + step;

@@ -345,7 +345,9 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
     int cw[TCOO_UNROLL];                                                               \
     _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j) {                          \
       const uint32_t q = (BASE) + lane + jstride * j;                                       \
-      while (c + 1 < T.nwin && q >= offL[c + 1]) ++c;                                  \
+      /* padding lanes (q >= send) must not move the cursor: in an inverted sweep it would run into */ \
+      /* the skipped window range and the next part's first elements would gather from there       */ \
+      while (q < send && c + 1 < T.nwin && q >= offL[c + 1]) ++c;                      \
       cw[j] = c;                                                                       \
     }                                                                                  \
     if (!(TCOO_ABL(T, 1))) {                                                             \
@@ -371,6 +373,7 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
       sbeg = b0; send = b1;
     }
     uint32_t base = sbeg + wave_off;
+    if (part == 1 && c < T.win_hi) c = T.win_hi;       // second part of an inverted sweep starts behind the skipped windows
     if (base < send) {
       TCOO_LOAD(idA, vA, base)
       while (true) {

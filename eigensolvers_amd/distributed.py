@@ -5,8 +5,9 @@ every vector is split the same way.  The only exchanges on the path are an all-g
 the operand slice before each operator application and a SUM all-reduce after each
 reduction, both issued by ``libhipeig.so`` through RCCL on its compute stream.  The host
 side only has to (a) agree on the row ranges and (b) distribute RCCL's 128-byte unique id,
-which is done here over ``torch.distributed`` (gloo) - torch is plumbing for the
-rendezvous, no tensor of the hot path ever goes through it.
+which is done here with a stdlib TCP exchange (``exchange_bytes``); host-side barriers and the
+few scalar reductions of a benchmark go through the library's own all-reduce
+(``DeviceGroup``).  Nothing in this package imports torch.
 """
 import contextlib
 import os
@@ -51,37 +52,132 @@ def world_from_env():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init_process_group_gloo():
-    """Join the gloo group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT."""
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        with stdout_to_stderr():
-            dist.init_process_group(backend="gloo")
-    return dist
+# ---- rendezvous: a stdlib TCP exchange of RCCL's 128-byte unique id ------------------------------
+# Under ``torch.distributed.run`` the launcher's own store already listens on MASTER_PORT, so the
+# exchange uses a port derived from it: rank 0 binds the first free one of a short deterministic
+# candidate list, the other ranks try the candidates until one answers with the expected greeting.
+_MAGIC = b"HIPEIG-RDZV-1"
 
 
-def broadcast_bytes(payload, nbytes, src=0):
-    """Broadcast a fixed-size byte string from ``src`` over the gloo group."""
-    import torch
-    import torch.distributed as dist
-    buf = torch.zeros(nbytes, dtype=torch.uint8)
-    if dist.get_rank() == src:
-        buf = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
-    dist.broadcast(buf, src=src)
-    return bytes(buf.numpy().tobytes())
+def _candidate_ports():
+    base = int(os.environ.get("HIPEIG_RDZV_PORT", "0"))
+    if base:
+        return [base]
+    mp = int(os.environ.get("MASTER_PORT", "29511"))
+    return [20000 + (mp * 7 + 13 + 101 * k) % 20000 for k in range(8)]
 
 
-def attach_rccl(ctx):
-    """Create the RCCL communicator of ``ctx`` for the current gloo group (collective)."""
-    import torch.distributed as dist
-    rank, world = dist.get_rank(), dist.get_world_size()
+def _run_token():
+    return (os.environ.get("TORCHELASTIC_RUN_ID", "none") + ":" + os.environ.get("MASTER_PORT", "29511")).encode()
+
+
+def exchange_bytes(payload, nbytes, rank, world, timeout=300.0):
+    """Rank 0 hands ``payload`` (``nbytes`` bytes) to every other rank over TCP on MASTER_ADDR; returns it.
+    No third-party module involved (the north star's "no PyTorch" covers the rendezvous too)."""
+    import socket
+    import time
+    if world == 1:
+        return bytes(payload)
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    token = _MAGIC + b"|" + _run_token()
+    if rank == 0:
+        srv = None
+        for port in _candidate_ports():
+            try:
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind((addr, port))
+                break
+            except OSError:
+                srv.close()
+                srv = None
+        if srv is None:
+            raise RuntimeError(f"rendezvous: none of the ports {_candidate_ports()} is free on {addr}")
+        srv.listen(world)
+        srv.settimeout(timeout)
+        served = set()
+        try:
+            while len(served) < world - 1:
+                conn, _ = srv.accept()
+                with conn:
+                    conn.settimeout(10.0)
+                    try:
+                        hello = conn.recv(256)
+                    except OSError:
+                        continue
+                    if not hello.startswith(token + b"|"):
+                        continue                              # a stranger on our port: ignore
+                    peer = int(hello[len(token) + 1:].decode())
+                    conn.sendall(token + b"|" + bytes(payload))
+                    served.add(peer)
+        finally:
+            srv.close()
+        return bytes(payload)
+    deadline = time.time() + timeout
+    while time.time() < deadline:
+        for port in _candidate_ports():
+            try:
+                with socket.create_connection((addr, port), timeout=2.0) as c:
+                    c.sendall(token + b"|" + str(rank).encode())
+                    buf = b""
+                    want = len(token) + 1 + nbytes
+                    while len(buf) < want:
+                        chunk = c.recv(want - len(buf))
+                        if not chunk:
+                            break
+                        buf += chunk
+                    if len(buf) == want and buf.startswith(token + b"|"):
+                        return buf[len(token) + 1:]
+            except OSError:
+                pass
+        time.sleep(0.05)
+    raise TimeoutError(f"rendezvous: rank {rank} got no unique id from rank 0 within {timeout:.0f} s")
+
+
+def attach_rccl(ctx, rank=None, world=None):
+    """Create the RCCL communicator of ``ctx`` for the ranks of the launcher's environment (collective).
+    Returns (rank, world)."""
+    if rank is None or world is None:
+        rank, world, _ = world_from_env()
     with stdout_to_stderr():
-        uid = ctx.new_unique_id() if rank == 0 else b"\0" * 128
-        uid = broadcast_bytes(uid, 128, src=0)
+        uid = ctx.new_unique_id() if rank == 0 else b""
+        uid = exchange_bytes(uid, 128, rank, world)
         ctx.attach_comm(world, rank, uid)
     return rank, world
+
+
+class DeviceGroup:
+    """Host-side helpers of a row-partitioned run built on the library's own collectives (RCCL through
+    ``hipeig_vec_allreduce``): a barrier and small MAX / SUM reductions of host scalars.  ``ctx`` must have
+    a communicator attached; with one rank everything is local."""
+
+    def __init__(self, ctx):
+        self.ctx, self.rank, self.world = ctx, ctx.rank, ctx.nranks
+        self._buf = ctx.alloc(max(self.world, 1)) if self.world > 1 else None
+
+    def allgather_scalar(self, x):
+        """[x of rank 0, x of rank 1, ...] on every rank (one SUM all-reduce of ``world`` doubles)."""
+        import ctypes as C
+        import numpy as np
+        from . import _lib
+        if self.world == 1:
+            return [float(x)]
+        host = np.zeros(self.world)
+        host[self.rank] = float(x)
+        _lib.call("hipeig_vec_upload", self.ctx.handle, self._buf.ptr, host.ctypes.data_as(C.c_void_p), self.world)
+        _lib.call("hipeig_vec_allreduce", self.ctx.handle, self._buf.ptr, self.world)
+        _lib.call("hipeig_vec_download", self.ctx.handle, host.ctypes.data_as(C.c_void_p), self._buf.ptr, self.world)
+        return [float(v) for v in host]
+
+    def allmax(self, x):
+        return max(self.allgather_scalar(x))
+
+    def allsum(self, x):
+        return sum(self.allgather_scalar(x))
+
+    def barrier(self):
+        self.ctx.synchronize()
+        self.allgather_scalar(0.0)
 
 
 class ContourReplicas:

@@ -425,8 +425,13 @@ class HipVector(AbstractVector):
 
     @staticmethod
     def orthogonalize_against_set(x, qs, lindep=LINDEP_DEFAULT_VALUE):
+        """numpyVector.py:121-145.  Default: the reference's own sweep - sequential modified Gram-Schmidt
+        with the division by q.q, ``None`` when what is left has x.x <= lindep - so the linear-dependency
+        exit fires where the reference's does.  ``options["orthogonalization"] = "cgs2"`` selects two
+        batched classical passes instead (one reduction per pass; its second pass changes the inner
+        product compared with ``lindep``, so that exit may fire at another iteration)."""
         new = x.copy()
-        method = _ORTHO_METHODS[x.options.get("orthogonalization", "cgs2")]
+        method = _ORTHO_METHODS[x.options.get("orthogonalization", "mgs")]
         ip = C.c_double()
         dep = C.c_int()
         tab, keep = _ptr_table([q._buf for q in qs]) if len(qs) else (None, None)

@@ -255,8 +255,13 @@ def inexactLanczosDiagonalization(H, v0: Union[AbstractVector, List[AbstractVect
                        ``checkpointDir/krylov_{cumIter}.npz`` after every iteration, keeping the
                        newest ``checkpointKeep`` files (0 = all);
     ``resumeFrom``     a checkpoint file, or a directory whose newest checkpoint is taken: the run
-                       continues after that iteration and reproduces the uninterrupted run
-                       (``v0`` then only provides the backend type, options and block size);
+                       continues after that iteration (``v0`` then only provides the backend type,
+                       options and block size) and reproduces the uninterrupted run - bit for bit when
+                       the backend's arithmetic is reproducible (HipVector: operator kernel variants 1-3,
+                       ``HipCsrOperator.set_variant(3)`` for large operators; the default variant 4 and
+                       the block kernels agree to rounding only); on a partitioned run all ranks take
+                       the newest iteration every rank has a file of, and run parameters that differ
+                       from the checkpoint's raise;
     ``thickRestart``   k > 0: a restart keeps k further Ritz vectors (next in ``pick`` order) in
                        front of the nBlock picked ones instead of discarding them."""
     if convertUnit != "au":
@@ -278,6 +283,7 @@ def inexactLanczosDiagonalization(H, v0: Union[AbstractVector, List[AbstractVect
             if path is None:
                 raise FileNotFoundError(f"no checkpoint in {resumeFrom}")
         resumed = _ckpt.load_checkpoint(path)
+        _ckpt.check_meta(resumed["meta"], sigma, L, eConv, _ckpt._partition_of(v0[0])[1], path)
         if resumed["status"].get("nBlock") != nBlock:
             raise ValueError(f"checkpoint block size {resumed['status'].get('nBlock')} != {nBlock}")
         if resumed["Y"].shape[1] != len(v0[0]):

@@ -95,7 +95,11 @@ def test_partitioned_runs_write_one_file_per_rank(tmp_path):
     st = {"cumIter": 7, "nBlock": 1, "ref": [np.array([1.0])], "residual": np.inf}
     name = ck.save_checkpoint(str(tmp_path), v, np.eye(2), np.eye(2), np.eye(2), np.ones(2), st)
     assert os.path.basename(name) == "krylov_000007.r1of4.npz"
-    assert ck.latest_checkpoint(str(tmp_path), 1, 4) == name and ck.latest_checkpoint(str(tmp_path), 0, 4) is None
+    assert ck.latest_checkpoint(str(tmp_path), 1, 4) is None             # ranks 0, 2, 3 have not written iteration 7 yet
+    for r in (0, 2, 3):
+        Ctx.rank = r
+        ck.save_checkpoint(str(tmp_path), v, np.eye(2), np.eye(2), np.eye(2), np.ones(2), st)
+    assert ck.latest_checkpoint(str(tmp_path), 1, 4) == name
     c = ck.load_checkpoint(name)
     assert c["status"]["residual"] == np.inf and c["meta"]["rank"] == 1
 
@@ -121,3 +125,31 @@ def test_thick_restart(gapped4000):
     assert not st_simple["isConverged"] and st_simple["cumIter"] == 45
     assert st_thick["isConverged"] and st_thick["cumIter"] < 45
     assert abs(ev_thick[0] - ev_s[0]) < 1e-5
+
+
+def test_partitioned_resume_uses_the_newest_iteration_all_ranks_have(tmp_path):
+    """ranks write and prune their own files; after a crash between two ranks' writes the
+    newest files differ per rank.  Every rank must resume from the same (newest complete) iteration."""
+    d = str(tmp_path)
+    for it, ranks in ((7, (0, 1, 2)), (8, (0, 1, 2)), (9, (0, 2))):          # rank 1 died before writing 9
+        for r in ranks:
+            open(ck.checkpoint_name(d, it, r, 3), "wb").close()
+    open(os.path.join(d, "krylov_000011.npz"), "wb").close()                 # an unpartitioned run's file: ignored
+    for r in range(3):
+        assert ck.latest_checkpoint(d, r, 3) == ck.checkpoint_name(d, 8, r, 3)
+    assert ck.latest_checkpoint(d, 0, 1) == os.path.join(d, "krylov_000011.npz")
+    os.remove(ck.checkpoint_name(d, 8, 2, 3))
+    assert ck.latest_checkpoint(d, 1, 3) == ck.checkpoint_name(d, 7, 1, 3)
+    assert ck.latest_checkpoint(d, 0, 2) is None
+
+
+def test_resume_refuses_other_run_parameters(tmp_path, gapped4000):
+    H, guess = gapped4000
+    d = str(tmp_path / "ck")
+    _run(H, guess, maxit=1, checkpointDir=d)
+    with pytest.raises(ValueError, match="sigma"):
+        ea.inexactLanczosDiagonalization(H, RefVector(guess.copy(), _opts()), 0.03, 5, 6, 1e-12, writeOut=False, resumeFrom=d)
+    with pytest.raises(ValueError, match="L="):
+        ea.inexactLanczosDiagonalization(H, RefVector(guess.copy(), _opts()), 0.02, 7, 6, 1e-12, writeOut=False, resumeFrom=d)
+    with pytest.raises(ValueError, match="eConv"):
+        ea.inexactLanczosDiagonalization(H, RefVector(guess.copy(), _opts()), 0.02, 5, 6, 1e-9, writeOut=False, resumeFrom=d)

@@ -1,4 +1,4 @@
-"""world_size-2 CPU rehearsal (gloo) of the row-partitioned path: the product's host driver
+"""world_size-2 CPU rehearsal (gloo, test-only stand-in for RCCL) of the row-partitioned path: the product's host driver
 runs on every rank with local slices, all ranks must take identical decisions and the
 result must equal the single-process oracle run."""
 import os
@@ -29,11 +29,11 @@ def _worker(rank, world, port, N, out_dir):
     from eigensolvers_amd import distributed as D
     from eigensolvers_amd.generators import gapped_csr_host, guess_vector
     from _dist_vector import DistRefVector, SlabOperator
-    dist = D.init_process_group_gloo()
+    import torch.distributed as dist                       # test infrastructure only: the CPU stand-in collectives
+    dist.init_process_group(backend="gloo")
     assert D.world_from_env() == (rank, world, rank)
-    # the byte broadcast used to ship RCCL's unique id
-    payload = bytes(range(128)) if rank == 0 else b"\0" * 128
-    assert D.broadcast_bytes(payload, 128, src=0) == bytes(range(128))
+    # the product's own rendezvous (stdlib TCP, no torch): how RCCL's 128-byte unique id travels
+    assert D.exchange_bytes(bytes(range(128)) if rank == 0 else b"", 128, rank, world) == bytes(range(128))
     ea.AbstractVector.register(DistRefVector)
     ranges = D.all_row_ranges(N, world)
     b, e = ranges[rank]
@@ -95,7 +95,8 @@ def _feast_worker(rank, world, port, out_dir):
     from conftest import load_golden
     from eigensolvers_amd import distributed as D
     from oracle.numpy_vector import RefVector
-    dist = D.init_process_group_gloo()
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo")
     ea.AbstractVector.register(RefVector)
     g = load_golden("feast_n100.npz")
     opts = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 1000, "linear_tol": 1e-2}}

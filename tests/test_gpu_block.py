@@ -185,6 +185,6 @@ def test_block_lanczos_block8_matches_reference_golden(hip, gapped4000):
         np.testing.assert_allclose(np.sort(ev[:8]), np.sort(g["ev"][:8]), rtol=float(g["ev_rtol"]), atol=0)
         if st["isConverged"]:
             res = hip.true_residual_norms(H, ev, Y, 8)
-            assert np.all(res < 1e-5)
+            assert np.all(res < 1e-3)            # eConv = 1e-8 on the eigenvalue ~ residual norm^2
             S = hip.HipVector.overlapMatrix(Y[:8])
             np.testing.assert_allclose(S, np.eye(8), atol=1e-7)
