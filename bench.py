@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 CSR-vector, 2 CSR-stream, 3/4 column-window blocked (wave / workgroup units)")
     ap.add_argument("--no-lanczos", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-block", action="store_true", help="skip the block-of-8 solve timing (BASELINE config #3, N = 1e6)")
     ap.add_argument("--lanczos-L", type=int, default=8)
     ap.add_argument("--lanczos-maxit", type=int, default=4)
     ap.add_argument("--lanczos-econv", type=float, default=1e-10)
@@ -166,6 +167,34 @@ def main(result):
                           "converged": bool(st["isConverged"]), "eigenvalue_change_residual": float(st["residual"]),
                           "true_residual_norm": float(res[0]), "minres_iters_last_solve": inner,
                           "L": a.lanczos_L, "maxit": a.lanczos_maxit, "eConv": a.lanczos_econv, "linear_tol": 1e-10}
+
+    # ---- BASELINE config #3 (N = 1e6, 32 nnz/row, block of 8): lock-step block solve vs eight single solves ----
+    if world == 1 and not a.no_block:
+        Nb = 1_000_000
+        Hb = ea.HipCsrOperator.generate(Nb, 32, seed=a.seed, ctx=ctx)
+        Qb = np.random.default_rng(5).standard_normal((Nb, 8))
+        Qb /= np.linalg.norm(Qb, axis=0)
+        ob = lambda: {"linearSystemArgs": {"linearSolver": "minres", "linearIter": 4000, "linear_tol": 1e-10}}
+        Xb = [ea.HipVector(Qb[:, j].copy(), ob(), ctx=ctx) for j in range(8)]
+        ea.HipVector.solveBlock(Hb, Xb, a.sigma)                          # builds the block layout, warms up
+        ctx.synchronize()
+        tb = time.perf_counter()
+        Wb = ea.HipVector.solveBlock(Hb, Xb, a.sigma)
+        ctx.synchronize()
+        tb = time.perf_counter() - tb
+        ts = time.perf_counter()
+        Sb = [ea.HipVector.solve(Hb, xb, a.sigma) for xb in Xb]
+        ctx.synchronize()
+        ts = time.perf_counter() - ts
+        itb = [w.last_solve_stats["iterations"] for w in Wb]
+        out["block8"] = {"N": Nb, "nnz": int(Hb.nnz), "kernel": Hb.block_info()["variant"], "iterations": itb,
+                         "iterations_equal_single": itb == [w.last_solve_stats["iterations"] for w in Sb],
+                         "block_seconds": round(tb, 4), "single_seconds": round(ts, 4),
+                         "solves_per_s": round(8 / tb, 2), "single_solves_per_s": round(8 / ts, 2),
+                         "ms_per_block_iteration": round(1e3 * tb / max(itb), 4), "speedup": round(ts / tb, 3),
+                         "max_rel_diff": float(max(ea.HipVector.linearCombination([Wb[j], Sb[j]], [1.0, -1.0]).norm() / Sb[j].norm()
+                                                   for j in range(8)))}
+        del Hb, Xb, Wb, Sb
 
     # ---- CPU baseline: scipy csr_matvec on a bounded row slab (rank 0, single GPU only) ----
     if rank == 0 and world == 1 and not a.no_cpu:

@@ -35,6 +35,7 @@ SIGNATURES = {
     "hipeig_comm_init": [_P, C.c_int, C.c_int, _P],
     "hipeig_comm_destroy": [_P],
     "hipeig_comm_info": [_P, _IP, _IP],
+    "hipeig_comm_stats": [_P, _I64P],
     "hipeig_comm_set_partitioned": [_P, C.c_int],
     "hipeig_vec_allreduce": [_P, _P, C.c_int64],
     "hipeig_loopback_group_create": [C.c_int, C.POINTER(C.c_void_p)],

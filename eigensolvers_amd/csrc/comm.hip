@@ -253,6 +253,13 @@ extern "C" int hipeig_comm_info(hipeig_ctx* c, int* nranks, int* rank) {
   return 0;
 }
 
+// stats[0] = collectives (operand all-gathers + all-reduces) the most recent hipeig_minres call issued on
+// this rank; stats[1..3] reserved.
+extern "C" int hipeig_comm_stats(hipeig_ctx* c, int64_t stats[4]) {
+  stats[0] = c->mr_collectives; stats[1] = stats[2] = stats[3] = 0;
+  return 0;
+}
+
 // SUM all-reduce of `count` doubles in place on the compute stream.
 int hipeig_allreduce_sum(hipeig_ctx* c, double* d_buf, int count) {
   if (!c->collectives) return 0;

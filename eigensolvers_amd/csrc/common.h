@@ -77,6 +77,7 @@ struct hipeig_ctx {
   void* loop;                // in-process loopback group (rehearsal backend), or null
   int nranks, rank;
   int collectives;           // 1 when reductions / operator applications must go through RCCL
+  int64_t mr_collectives;    // collectives issued by the most recent hipeig_minres call (all-gathers + all-reduces)
   double* x_full;            // all-gathered operand of the operator
   int64_t x_full_n;
   int64_t* row_counts;       // rows per rank (host), length nranks

@@ -34,18 +34,26 @@ struct MinresRowEpilogue {
   const double* __restrict__ r2l;   // local slice of r2 (v = s*r2)
   const double* __restrict__ r1;
   double* __restrict__ y;
+  double* yy;                       // fused (distributed) form: running <y,y> of this thread, else null
   __device__ __forceinline__ void row(int64_t r, double sum, double& acc) const {
     const double v = s * r2l[r];
     double yv = sign * (mul_rn(sigma, v) - s * sum);
     if (use_r1) yv -= c1 * r1[r];
     y[r] = yv;
     acc = fma(v, yv, acc);
+    if (yy) *yy = fma(yv, yv, *yy);
   }
 };
 
 // VARIANT 1-4: the operator sweep of that layout.  VARIANT 5: the combine step of a split TCOO-W sweep
 // (T.raw_out holds T.part_base slabs of raw sums, see spmv_device.h) - same prologue, same epilogue.
-template <int VARIANT>
+//
+// FUSED = 1 is the form of a row-partitioned run (one fused, lagged reduction per
+// iteration).  The sweep leaves TWO partial sums per workgroup, <v,y> and <y,y> of the y it has just
+// written, in partials[b] and partials[HIPEIG_MAX_PARTIALS + b]; beta_{k+1}^2 = <y - alfa v, y - alfa v>
+// = <y,y> - alfa^2 then needs no second reduction (v is a unit vector), and the stopping tests of the
+// previous iteration move to the next kernel, where <x,x> arrives with the same all-reduce.
+template <int VARIANT, int FUSED = 0>
 __global__ void __launch_bounds__(VARIANT == 4 ? TCOOW_THREADS : HIPEIG_BLOCK)
 minres_ka_kernel(CsrView A, TcooView T, const double* __restrict__ xg, MinresArgs a, const MinresState* __restrict__ Sin,
                  MinresState* __restrict__ Sout, const double* __restrict__ r2l,
@@ -54,8 +62,10 @@ minres_ka_kernel(CsrView A, TcooView T, const double* __restrict__ xg, MinresArg
   __shared__ double red[16];
   extern __shared__ double tcoo_lds[];
   MinresState S = *Sin;
-  const double xx = (S.itn > 0 && !S.done) ? sum_or_value(a.pD, a.nD, red) : 0.0;
-  minres_tests(S, xx, a);
+  if (!FUSED) {
+    const double xx = (S.itn > 0 && !S.done) ? sum_or_value(a.pD, a.nD, red) : 0.0;
+    minres_tests(S, xx, a);
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
   if (S.done) return;
   MinresRowEpilogue epi;
@@ -63,7 +73,8 @@ minres_ka_kernel(CsrView A, TcooView T, const double* __restrict__ xg, MinresArg
   epi.use_r1 = S.itn >= 1;
   epi.c1 = epi.use_r1 ? S.beta / S.oldb : 0.0;
   epi.r2l = r2l; epi.r1 = r1; epi.y = y;
-  double acc = 0.0;
+  double acc = 0.0, acc_yy = 0.0;
+  epi.yy = FUSED ? &acc_yy : nullptr;
   if (VARIANT == 5) tcoow_combine_sweep(T.raw_out, T.part_base, T.part_stride, T.nrows, epi, acc);
   else if (VARIANT == 4) tcoo_wg_sweep(T, xg, epi, acc, tcoo_lds);
   else if (VARIANT == 3) tcoo_sweep(T, xg, epi, acc, tcoo_lds);
@@ -72,6 +83,66 @@ minres_ka_kernel(CsrView A, TcooView T, const double* __restrict__ xg, MinresArg
   if (VARIANT == 4 && T.raw_out) return;                   // raw slabs only: the combine launch owns the partials
   acc = block_reduce_sum(acc, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = acc;      // the host offsets `partials` per sweep
+  if (FUSED) {
+    acc_yy = block_reduce_sum(acc_yy, red);
+    if (threadIdx.x == 0) partials[HIPEIG_MAX_PARTIALS + blockIdx.x] = acc_yy;
+  }
+}
+
+// Fused second half of an iteration of a row-partitioned run: stopping tests of the PREVIOUS iteration
+// (its <x,x> has just arrived), then KC and KD in one pass: y -= (alfa/beta) r2, w, x.  All three sums are
+// all-reduced records of HIPEIG_MAX_PARTIALS slots (unused slots are zero on every rank).
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+minres_kcd_fused_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, MinresState* __restrict__ Sout,
+                        const double* __restrict__ r2, double* __restrict__ y, const double* __restrict__ w1,
+                        const double* __restrict__ w2, double* __restrict__ w, double* __restrict__ x,
+                        double* __restrict__ partials) {
+  __shared__ double red[4];
+  MinresState S = *Sin;
+  if (!S.done) {
+    const double xx = S.itn > 0 ? block_sum_partials(a.pD, a.nD, red) : 0.0;
+    minres_tests(S, xx, a);
+  }
+  if (S.done) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
+    return;
+  }
+  S.alfa = block_sum_partials(a.pA, a.nA, red);
+  const double yy = block_sum_partials(a.pC, a.nC, red);
+  const double c = S.alfa / S.beta;
+  const double s_old = S.s;
+  minres_advance(S, fmax(yy - S.alfa * S.alfa, 0.0));
+  if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
+  const double oldeps = S.oldeps, delta = S.delta, denom = S.denom, phi = S.phi;
+  const int64_t n2 = n >> 1;
+  const double2* r22 = reinterpret_cast<const double2*>(r2);
+  const double2* w12 = reinterpret_cast<const double2*>(w1);
+  const double2* w22 = reinterpret_cast<const double2*>(w2);
+  double2* y2 = reinterpret_cast<double2*>(y);
+  double2* wn2 = reinterpret_cast<double2*>(w);
+  double2* x2 = reinterpret_cast<double2*>(x);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    const double2 rv = r22[i], a1 = w12[i], a2 = w22[i];
+    double2 yv = y2[i], xv = x2[i], wn;
+    yv.x -= c * rv.x; yv.y -= c * rv.y;
+    wn.x = (s_old * rv.x - oldeps * a1.x - delta * a2.x) * denom;
+    wn.y = (s_old * rv.y - oldeps * a1.y - delta * a2.y) * denom;
+    xv.x += phi * wn.x; xv.y += phi * wn.y;
+    y2[i] = yv; wn2[i] = wn; x2[i] = xv;
+    acc = fma(xv.x, xv.x, acc); acc = fma(xv.y, xv.y, acc);
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    y[i] -= c * r2[i];
+    const double wn = (s_old * r2[i] - oldeps * w1[i] - delta * w2[i]) * denom;
+    const double xv = x[i] + phi * wn;
+    w[i] = wn; x[i] = xv;
+    acc = fma(xv, xv, acc);
+  }
+  acc = block_reduce_sum(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
@@ -161,12 +232,6 @@ __global__ void minres_check_kernel(MinresArgs a, MinresState* __restrict__ S0) 
   if (threadIdx.x == 0) *S0 = S;
 }
 
-__global__ void sum_partials_kernel(const double* __restrict__ p, int count, double* __restrict__ out) {
-  __shared__ double red[4];
-  const double v = block_sum_partials(p, count, red);
-  if (threadIdx.x == 0) *out = v;
-}
-
 extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double sign, const double* b,
                              double* x, double rtol, int maxiter, int* info, double out_stats[8]) {
   HIPEIG_REQUIRE(info != nullptr, "null info");
@@ -222,7 +287,6 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   double* pC = c->d_partials + HIPEIG_MAX_PARTIALS;
   double* pD = c->d_partials + 2 * HIPEIG_MAX_PARTIALS;
   const bool dist = c->collectives != 0;
-  double* red = c->d_scalars + 2048;    // reduced sums for the distributed path
   MinresArgs a;
   a.sigma = sigma; a.sign = sign; a.rtol = rtol; a.maxiter = maxiter;
   const bool split = (variant == 4) && A->w_csplit > 1;      // raw slabs + combine launch
@@ -230,9 +294,56 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
                     : (variant == 3) ? (A->t_nunits + gA * 4 - 1) / (gA * 4) : 1;
   HIPEIG_REQUIRE(nsweepA * gA <= HIPEIG_MAX_PARTIALS, "too many sweeps for the partial-sum buffer");
   const int nPA = split ? gE : gA * nsweepA;                 // partial <v,y> sums one iteration leaves in pA
-  a.pA = dist ? red + 0 : pA; a.nA = dist ? 1 : nPA;
-  a.pC = dist ? red + 1 : pC; a.nC = dist ? 1 : gE;
-  a.pD = dist ? red + 2 : pD; a.nD = dist ? 1 : gE;
+  // Row-partitioned run: the three partial-sum areas are ONE all-reduce record of 3 x HIPEIG_MAX_PARTIALS
+  // doubles ([<v,y> | <y,y> | <x,x> of the previous iteration], unused slots zero), reduced slot by slot
+  // over the ranks once per iteration; the kernels' prologues then sum the slots in fixed order, so every
+  // rank obtains identical scalars without any reduction launch of its own.
+  double* pE = c->d_partials + 3 * HIPEIG_MAX_PARTIALS;      // copy of the <x,x> area for the end-of-chunk check
+  a.pA = pA; a.nA = dist ? HIPEIG_MAX_PARTIALS : nPA;
+  a.pC = pC; a.nC = dist ? HIPEIG_MAX_PARTIALS : gE;
+  a.pD = pD; a.nD = dist ? HIPEIG_MAX_PARTIALS : gE;
+  if (dist) HIPEIG_CHECK(hipMemsetAsync(pA, 0, (size_t)4 * HIPEIG_MAX_PARTIALS * sizeof(double), c->stream));
+  c->mr_collectives = 0;
+
+  // The operator sweep of iteration k (all variants); FUSED: also leaves the <y,y> partials.
+  auto enqueue_ka = [&](int fused, double* r2, double* r1, double* yb) -> int {
+    const double* xg = nullptr;
+    TcooView tv = tview;
+#define KA_LAUNCH(VAR, GRID, THREADS, LDS, TV, PARTS)                                                               \
+    do {                                                                                                            \
+      if (fused) hipLaunchKernelGGL((minres_ka_kernel<VAR, 1>), dim3(GRID), dim3(THREADS), LDS, c->stream, view, TV, xg, a, V + 0, V + 1, r2, r1, yb, PARTS); \
+      else hipLaunchKernelGGL((minres_ka_kernel<VAR, 0>), dim3(GRID), dim3(THREADS), LDS, c->stream, view, TV, xg, a, V + 0, V + 1, r2, r1, yb, PARTS);      \
+    } while (0)
+    if (variant == 4) {
+      int ncombine = 0;                                           // local windows under the all-gather
+      if (hipeig_tcoow_prepare(c, A, r2, &tv, &xg, &ncombine)) return 4;
+      if (c->collectives) ++c->mr_collectives;                    // the operand all-gather
+      for (int sw = 0; sw < nsweepA; ++sw) {
+        tv.unit_begin = sw * gA;
+        KA_LAUNCH(4, gA, TCOOW_THREADS, hipeig_tcoow_lds_bytes(A), tv, pA + sw * gA);
+      }
+      if (ncombine) {
+        TcooView tc = tv;
+        tc.part_base = ncombine;                                  // number of slabs to add
+        KA_LAUNCH(5, gE, HIPEIG_BLOCK, 0, tc, pA);
+      }
+      return 0;
+    }
+    if (hipeig_allgather_x(c, r2, n, A->col_stride, &xg)) return 4;
+    if (c->collectives) ++c->mr_collectives;
+    if (variant == 3) {
+      for (int sw = 0; sw < nsweepA; ++sw) {       // one launch per sweep; partials side by side
+        tv.unit_begin = sw * gA * 4;
+        KA_LAUNCH(3, gA, HIPEIG_BLOCK, hipeig_tcoo_lds_bytes(A), tv, pA + sw * gA);
+      }
+    } else if (variant == 1) {
+      KA_LAUNCH(1, gA, HIPEIG_BLOCK, 0, tview, pA);
+    } else {
+      KA_LAUNCH(2, gA, HIPEIG_BLOCK, 0, tview, pA);
+    }
+#undef KA_LAUNCH
+    return 0;
+  };
 
   // One iteration's launches on the compute stream (buffer roles rotate with period 3).
   auto enqueue_iteration = [&](int k) -> int {
@@ -242,50 +353,42 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
     double* wn = W[k % 3];
     double* w1 = W[(k + 1) % 3];
     double* w2 = W[(k + 2) % 3];
-    const double* xg = nullptr;
-    TcooView tv = tview;
-    if (variant == 4) {
-      int ncombine = 0;                                           // local windows under the all-gather
-      if (hipeig_tcoow_prepare(c, A, r2, &tv, &xg, &ncombine)) return 4;
-      for (int sw = 0; sw < nsweepA; ++sw) {
-        tv.unit_begin = sw * gA;
-        hipLaunchKernelGGL((minres_ka_kernel<4>), dim3(gA), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, view, tv, xg, a, V + 0, V + 1, r2, r1, yb, pA + sw * gA);
-      }
-      if (ncombine) {
-        TcooView tc = tv;
-        tc.part_base = ncombine;                                  // number of slabs to add
-        hipLaunchKernelGGL((minres_ka_kernel<5>), dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, view, tc, xg, a, V + 0, V + 1, r2, r1, yb, pA);
-      }
-    } else if (hipeig_allgather_x(c, r2, n, A->col_stride, &xg)) {
-      return 4;
-    } else if (variant == 3) {
-      for (int sw = 0; sw < nsweepA; ++sw) {       // one launch per sweep; partials side by side
-        tv.unit_begin = sw * gA * 4;
-        hipLaunchKernelGGL((minres_ka_kernel<3>), dim3(gA), dim3(HIPEIG_BLOCK), hipeig_tcoo_lds_bytes(A), c->stream, view, tv, xg, a, V + 0, V + 1, r2, r1, yb, pA + sw * gA);
-      }
-    } else if (variant == 1)
-      hipLaunchKernelGGL((minres_ka_kernel<1>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream, view, tview, xg, a, V + 0, V + 1, r2, r1, yb, pA);
-    else
-      hipLaunchKernelGGL((minres_ka_kernel<2>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream, view, tview, xg, a, V + 0, V + 1, r2, r1, yb, pA);
     if (dist) {
-      hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pA, nPA, red + 0);
-      if (hipeig_allreduce_sum(c, red + 0, 1)) return 4;
+      // all-gather + sweep, ONE all-reduce, fused update: 2 collectives and 2 (+ sweeps) launches
+      if (enqueue_ka(1, r2, r1, yb)) return 4;
+      if (hipeig_allreduce_sum(c, pA, 3 * HIPEIG_MAX_PARTIALS)) return 4;
+      ++c->mr_collectives;
+      hipLaunchKernelGGL(minres_kcd_fused_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 1, V + 0, r2, yb, w1, w2, wn, xw, pD);
+      return 0;
     }
+    if (enqueue_ka(0, r2, r1, yb)) return 4;
     hipLaunchKernelGGL(minres_kc_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 1, V + 2, r2, yb, pC);
-    if (dist) {
-      hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pC, gE, red + 1);
-      if (hipeig_allreduce_sum(c, red + 1, 1)) return 4;
-    }
     hipLaunchKernelGGL(minres_kd_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 2, V + 0, r2, w1, w2, wn, xw, pD);
-    if (dist) {
-      hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pD, gE, red + 2);
-      if (hipeig_allreduce_sum(c, red + 2, 1)) return 4;
-    }
     return 0;
   };
+  // diagnostic knobs for the rocprofv3-inside-capture question (profiles/r02_hipgraph_under_rocprofv3.txt):
+  // HIPEIG_GRAPH_COPY=0 keeps the device-to-host copy of the state record OUT of the captured graph,
+  // HIPEIG_GRAPH_MODE=0/2 captures in global / relaxed instead of thread-local mode
+  const char* gc_env = getenv("HIPEIG_GRAPH_COPY");
+  const bool graph_copy_node = !(gc_env && atoi(gc_env) == 0);
+  const char* gm_env = getenv("HIPEIG_GRAPH_MODE");
+  const int graph_mode = gm_env ? atoi(gm_env) : 1;
+  bool capturing = false;
+  const bool gtrace = getenv("HIPEIG_GRAPH_TRACE") != nullptr;       // stderr markers around the graph API calls
+#define GTRACE(msg) do { if (gtrace) { fprintf(stderr, "[hipeig graph] %s\n", msg); fflush(stderr); } } while (0)
   auto enqueue_check = [&]() -> int {
-    hipLaunchKernelGGL(minres_check_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, a, V + 0);
-    HIPEIG_CHECK(hipMemcpyAsync(h, V, sizeof(MinresState), hipMemcpyDeviceToHost, c->stream));
+    MinresArgs ac = a;
+    if (dist) {
+      // the last iteration's <x,x> has not been through an all-reduce yet; reduce a COPY, the area itself
+      // is reduced (once) with the next iteration's record
+      HIPEIG_CHECK(hipMemcpyAsync(pE, pD, (size_t)HIPEIG_MAX_PARTIALS * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      if (hipeig_allreduce_sum(c, pE, HIPEIG_MAX_PARTIALS)) return 4;
+      ++c->mr_collectives;
+      ac.pD = pE;
+    }
+    hipLaunchKernelGGL(minres_check_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, ac, V + 0);
+    if (!capturing || graph_copy_node)
+      HIPEIG_CHECK(hipMemcpyAsync(h, V, sizeof(MinresState), hipMemcpyDeviceToHost, c->stream));
     return 0;
   };
 
@@ -309,13 +412,19 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
     key.maxiter = maxiter; key.sigma = sigma; key.sign = sign; key.rtol = rtol;
     const int gchunk = 18;
     if (!c->mr_graph || c->mr_graph_key_bytes != sizeof(key) || memcmp(c->mr_graph_key, &key, sizeof(key)) != 0) {
-      if (c->mr_graph) { hipGraphExecDestroy(c->mr_graph); c->mr_graph = nullptr; }
+      if (c->mr_graph) { GTRACE("hipGraphExecDestroy"); hipGraphExecDestroy(c->mr_graph); c->mr_graph = nullptr; }
       hipGraph_t g = nullptr;
-      HIPEIG_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      GTRACE("hipStreamBeginCapture");
+      HIPEIG_CHECK(hipStreamBeginCapture(c->stream, graph_mode == 0 ? hipStreamCaptureModeGlobal
+                                                    : graph_mode == 2 ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
+      capturing = true;
       int rc = 0;
       for (int k = 0; k < gchunk && rc == 0; ++k) rc = enqueue_iteration(k);
       if (rc == 0) rc = enqueue_check();
+      GTRACE("hipStreamEndCapture");
       const hipError_t ce = hipStreamEndCapture(c->stream, &g);
+      capturing = false;
+      GTRACE("hipGraphInstantiate");
       if (rc) { if (g) hipGraphDestroy(g); return rc; }
       HIPEIG_CHECK(ce);
       const hipError_t ie = hipGraphInstantiate(&c->mr_graph, g, nullptr, nullptr, 0);
@@ -327,7 +436,10 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
       c->mr_graph_key_bytes = sizeof(key);
     }
     for (int k = 0; k < maxiter; k += gchunk) {
+      GTRACE("hipGraphLaunch");
       HIPEIG_CHECK(hipGraphLaunch(c->mr_graph, c->stream));
+      GTRACE("hipGraphLaunch returned");
+      if (!graph_copy_node) HIPEIG_CHECK(hipMemcpyAsync(h, V, sizeof(MinresState), hipMemcpyDeviceToHost, c->stream));
       HIPEIG_CHECK(hipStreamSynchronize(c->stream));
       if (h->done) break;
     }

@@ -262,7 +262,13 @@ class HipCsrOperator:
 
 
 class HipVector(AbstractVector):
-    """Device-resident fp64 vector with the NumpyVector interface."""
+    """Device-resident fp64 vector with the NumpyVector interface.  A complex array gives a
+    ``HipComplexVector`` (two real halves), the counterpart of a complex-dtype NumpyVector."""
+
+    def __new__(cls, array=None, options=None, ctx=None):
+        if cls is HipVector and not isinstance(array, DeviceBuffer) and np.iscomplexobj(array):
+            return HipComplexVector(array, options, ctx=ctx)
+        return super().__new__(cls)
 
     def __init__(self, array, options=None, ctx=None):
         given = {} if options is None else options
@@ -273,8 +279,8 @@ class HipVector(AbstractVector):
             host = np.ascontiguousarray(array, dtype=np.float64)
             if host.ndim != 1:
                 raise ValueError("HipVector holds 1-D vectors")
-            if np.iscomplexobj(array):
-                raise TypeError("HipVector is real fp64 (complex128 is the FEAST follow-up)")
+            if np.iscomplexobj(array):               # only reachable from a subclass: HipVector(...) itself dispatches
+                raise TypeError("a real HipVector cannot hold complex data; use HipComplexVector")
             self.ctx = ctx or HipContext.default()
             self._buf = self.ctx.alloc(host.size)
             _lib.call("hipeig_vec_upload", self.ctx.handle, self._buf.ptr,
@@ -478,6 +484,10 @@ class HipVector(AbstractVector):
         res.last_solve_stats = {"iterations": int(stats[0]), "istop": int(stats[1]), "rnorm": stats[2],
                                 "Anorm": stats[3], "ynorm": stats[4], "test1": stats[5],
                                 "test2": stats[6], "Acond": stats[7]}
+        if b.ctx.nranks > 1 or os.environ.get("HIPEIG_FORCE_COLLECTIVES", "0") not in ("", "0"):
+            cs = (C.c_int64 * 4)()
+            _lib.call("hipeig_comm_stats", b.ctx.handle, cs)
+            res.last_solve_stats["collectives"] = int(cs[0])
         b.last_solve_stats = res.last_solve_stats
         if info.value != 0:
             # numpyVector.py:175-177: the warning is escalated to an exception
@@ -529,7 +539,7 @@ class HipVector(AbstractVector):
             raise NotImplementedError("complex shifts need linearSolver='gcrotmk' on the device "
                                       f"(got {o['linearSolver']!r}; minres is for Hermitian systems)")
         from .gcrotmk import gcrotmk_device
-        ctx, n = b.ctx, b._buf.n
+        ctx, n = b.ctx, len(b)
         sgn = -1.0 if reverseGF else 1.0
 
         def matvec(v):                                  # sgn * ((zr + i zi)(vr + i vi) - H vr - i H vi)
@@ -540,9 +550,14 @@ class HipVector(AbstractVector):
             _lib.call("hipeig_axpby", ctx.handle, n, sgn * z.imag, v[0].ptr, 1.0, out_i.ptr)
             return (out_r, out_i)
 
-        zero = ctx.alloc(n)
-        _lib.call("hipeig_vec_fill", ctx.handle, zero.ptr, n, 0.0)
-        x, conv, gstats = gcrotmk_device(ctx, matvec, (b._buf, zero), n, rtol=float(o["linear_tol"]),
+        if isinstance(b, HipComplexVector):
+            rhs = (b.re._buf, b.im._buf)
+            b = b.re
+        else:
+            zero = ctx.alloc(n)
+            _lib.call("hipeig_vec_fill", ctx.handle, zero.ptr, n, 0.0)
+            rhs = (b._buf, zero)
+        x, conv, gstats = gcrotmk_device(ctx, matvec, rhs, n, rtol=float(o["linear_tol"]),
                                          atol=float(o["linear_atol"]), maxiter=int(o["linearIter"]),
                                          complex_pairs=True)
         res = HipComplexVector(b._new(x[0]), b._new(x[1]))
@@ -606,32 +621,60 @@ class HipVector(AbstractVector):
         return M
 
 
-class HipComplexVector:
-    """A complex128 vector as two real ``HipVector`` halves - what ``solve`` returns for a complex
-    shift and what a complex scalar times a ``HipVector`` gives.  It carries just what the FEAST
-    contour step needs (feast.py:90-92): scaling by a scalar, ``real``/``conjugate``, norms and a
-    host copy.  Interleaved complex kernels are the planned replacement."""
+class HipComplexVector(AbstractVector):
+    """complex128 vector on the device: two real fp64 halves (``re``, ``im``), every operation built from
+    the real kernels on the halves (the operator is real, so ``H (a + i b) = H a + i H b``).
 
-    def __init__(self, re, im):
-        self.re, self.im = re, im
-        self.options = re.options
-        self.ctx = re.ctx
+    It is what ``HipVector(array)`` returns for a complex array - the counterpart of a ``NumpyVector`` with a
+    complex dtype (numpyVector.py:25-28, 89-93: ``vdot`` conjugates ``self`` unless ``conjugate=False``) -,
+    what ``HipVector.solve`` returns for a complex shift (feast.py:90) and what a complex scalar times a
+    ``HipVector`` gives (feast.py:91-92).  Same constructor convention as the other backends:
+    ``HipComplexVector(complex_ndarray, options)``; internally also ``HipComplexVector(re_vec, im_vec)``."""
+
+    def __init__(self, re, im=None, ctx=None):
+        if isinstance(re, HipVector):
+            self.re, self.im = re, im
+        else:
+            host = np.asarray(re, dtype=np.complex128)
+            opts = im if isinstance(im, dict) or im is None else None
+            self.re = HipVector(np.ascontiguousarray(host.real), opts, ctx=ctx)
+            self.im = HipVector(np.ascontiguousarray(host.imag), self.re.options, ctx=ctx)
+        self.options = self.re.options
+        self.ctx = self.re.ctx
+        self.size = self.re.size
+        self.shape = self.re.shape
         self.last_solve_stats = None
 
-    hasExactAddition = True
-    maxD = 0
+    @staticmethod
+    def fromArray(template, array):
+        return HipComplexVector(np.asarray(array, dtype=np.complex128), template.options, ctx=template.ctx)
+
+    @staticmethod
+    def _parts(v):
+        """(re, im) halves of a complex or real device vector (im is None for a real one)."""
+        return (v.re, v.im) if isinstance(v, HipComplexVector) else (v, None)
+
+    # ---- properties ----------------------------------------------------------------
+    @property
+    def hasExactAddition(self):
+        return True
 
     @property
     def dtype(self):
         return np.dtype(np.complex128)
 
-    def __len__(self):
-        return len(self.re)
+    @property
+    def maxD(self):
+        return 0
 
     @property
     def array(self):
         return self.re.array + 1j * self.im.array
 
+    def __len__(self):
+        return len(self.re)
+
+    # ---- arithmetic ------------------------------------------------------------------
     def _scaled(self, alpha):
         a = complex(alpha)
         re = HipVector.linearCombination([self.re, self.im], [a.real, -a.imag])
@@ -641,10 +684,27 @@ class HipComplexVector:
     def __mul__(self, other):
         return self._scaled(other)
 
-    __rmul__ = __mul__
+    def __rmul__(self, other):
+        return self._scaled(other)
 
     def __truediv__(self, other):
         return self._scaled(1.0 / complex(other))
+
+    def __imul__(self, other):
+        raise NotImplementedError          # numpyVector.py:66-67
+
+    def __itruediv__(self, other):
+        raise NotImplementedError          # numpyVector.py:69-70
+
+    # ---- instance methods ------------------------------------------------------------
+    def norm(self):
+        return float(np.hypot(self.re.norm(), self.im.norm()))
+
+    def normalize(self):
+        nrm = self.norm()
+        for half in (self.re, self.im):    # in place: aliases of this vector see the change (numpyVector.py:76-78)
+            _lib.call("hipeig_divide", self.ctx.handle, half._buf.n, nrm, half._buf.ptr, half._buf.ptr)
+        return self
 
     def real(self):
         return self.re.copy()
@@ -652,8 +712,116 @@ class HipComplexVector:
     def conjugate(self):
         return HipComplexVector(self.re.copy(), self.im * -1.0)
 
-    def norm(self):
-        return float(np.hypot(self.re.norm(), self.im.norm()))
+    def vdot(self, other, conjugate=True):
+        """numpyVector.py:89-93: ``np.vdot`` (self conjugated) or the bilinear ``np.dot``."""
+        br, bi = self._parts(other)
+        rr, ir = self.re.vdot(br), self.im.vdot(br)
+        ri, ii = (self.re.vdot(bi), self.im.vdot(bi)) if bi is not None else (0.0, 0.0)
+        if conjugate:
+            return complex(rr + ii, ri - ir)
+        return complex(rr - ii, ri + ir)
 
     def copy(self):
         return HipComplexVector(self.re.copy(), self.im.copy())
+
+    def applyOp(self, other):
+        return HipComplexVector(self.re.applyOp(other), self.im.applyOp(other))
+
+    def compress(self):
+        return self
+
+    # ---- static hooks ------------------------------------------------------------------
+    @staticmethod
+    def linearCombination(vectors, coeffs):
+        assert len(vectors) == len(coeffs)
+        vs_re, cs_re, vs_im, cs_im = [], [], [], []
+        for v, c in zip(vectors, coeffs):
+            c = complex(c)
+            vr, vi = HipComplexVector._parts(v)
+            vs_re.append(vr); cs_re.append(c.real)          # Re: cr vr - ci vi
+            vs_im.append(vr); cs_im.append(c.imag)          # Im: ci vr + cr vi
+            if vi is not None:
+                vs_re.append(vi); cs_re.append(-c.imag)
+                vs_im.append(vi); cs_im.append(c.real)
+        return HipComplexVector(HipVector.linearCombination(vs_re, cs_re), HipVector.linearCombination(vs_im, cs_im))
+
+    @staticmethod
+    def orthogonalize_against_set(x, qs, lindep=LINDEP_DEFAULT_VALUE):
+        """The reference's sweep, numpyVector.py:121-145, with its bilinear products."""
+        for q in qs:
+            t1 = x.vdot(q, conjugate=False)
+            t2 = q.vdot(q, conjugate=False)
+            x = HipComplexVector.linearCombination([x, q * (t1 / t2)], [1.0, -1.0])
+        ip = np.complex128(x.vdot(x, conjugate=False))
+        if ip > lindep:                                       # NumPy orders complex numbers lexicographically, as in the reference
+            return x / np.sqrt(ip)
+        return None
+
+    @staticmethod
+    def solve(H, b, sigma, x0=None, opType="her", reverseGF=False):
+        """(sigma I - H) x = b for a complex right-hand side.  Real shift with MINRES: the real operator acts on
+        the halves separately, so the two real systems are solved in lock step (``solveBlock``); everything
+        else is complex GCROT on (re, im) pairs, like a complex shift."""
+        if not isinstance(H, HipCsrOperator):
+            raise TypeError("HipComplexVector.solve needs a HipCsrOperator (device-resident CSR)")
+        if x0 is not None:
+            raise NotImplementedError("solve starts from a zero guess (the solvers pass none)")
+        o = b.options["linearSystemArgs"]
+        is_complex_shift = isinstance(sigma, complex) or np.iscomplexobj(sigma)
+        if o["linearSolver"] == "minres" and not is_complex_shift:
+            xr, xi = HipVector.solveBlock(H, [b.re, b.im], sigma, reverseGF=reverseGF)
+            res = HipComplexVector(xr, xi)
+            res.last_solve_stats = b.last_solve_stats = {"re": xr.last_solve_stats, "im": xi.last_solve_stats,
+                                                         "iterations": max(xr.last_solve_stats["iterations"],
+                                                                           xi.last_solve_stats["iterations"])}
+            return res
+        return HipVector._solve_complex(H, b, complex(sigma), o, reverseGF)
+
+    @staticmethod
+    def _gram(A, B):
+        """A^H B for lists of (possibly complex) vectors: four real Gram blocks on the matrix cores."""
+        ar = [HipComplexVector._parts(v)[0] for v in A]
+        ai = [HipComplexVector._parts(v)[1] for v in A]
+        br = [HipComplexVector._parts(v)[0] for v in B]
+        bi = [HipComplexVector._parts(v)[1] for v in B]
+
+        def g(X, Y):
+            if any(v is None for v in X) or any(v is None for v in Y):
+                return np.zeros((len(X), len(Y)))
+            out = np.empty((len(X), len(Y)))
+            tx, k1 = _ptr_table([v._buf for v in X])
+            ty, k2 = _ptr_table([v._buf for v in Y])
+            _lib.call("hipeig_gram", X[0].ctx.handle, X[0]._buf.n, len(X), tx, len(Y), ty, out.ctypes.data_as(C.POINTER(C.c_double)))
+            return out
+        return (g(ar, br) + g(ai, bi)) + 1j * (g(ar, bi) - g(ai, br))
+
+    @staticmethod
+    def overlapMatrix(vectors):
+        S = HipComplexVector._gram(vectors, vectors)
+        return np.triu(S) + np.triu(S, 1).conj().T           # upper triangle mirrored, numpyVector.py:199-202
+
+    @staticmethod
+    def matrixRepresentation(operator, vectors):
+        kets = [v.applyOp(operator) for v in vectors]
+        M = HipComplexVector._gram(vectors, kets)
+        return np.tril(M) + np.tril(M, -1).conj().T           # lower triangle mirrored, numpyVector.py:186-189
+
+    @staticmethod
+    def extendOverlapMatrix(vectors, overlap):
+        col = HipComplexVector._gram(vectors, vectors[-1:])[:, 0]
+        m = len(vectors)
+        S = np.empty((m, m), dtype=np.complex128)
+        S[:m - 1, :m - 1] = overlap
+        S[:, m - 1] = col
+        S[m - 1, :m - 1] = col[:-1].conj()
+        return S
+
+    @staticmethod
+    def extendMatrixRepresentation(operator, vectors, opMat):
+        col = HipComplexVector._gram(vectors, [vectors[-1].applyOp(operator)])[:, 0]
+        m = len(vectors)
+        M = np.empty((m, m), dtype=np.complex128)
+        M[:m - 1, :m - 1] = opMat
+        M[:, m - 1] = col
+        M[m - 1, :m - 1] = col[:-1].conj()
+        return M

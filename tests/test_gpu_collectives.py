@@ -50,7 +50,12 @@ w4 = ea.HipVector.solve(H2, b2, 0.02); it4 = w4.last_solve_stats["iterations"]
 H2.set_variant(2)
 w2 = ea.HipVector.solve(H2, b2, 0.02); it2 = w2.last_solve_stats["iterations"]
 d = ea.HipVector.linearCombination([w4, w2], [1.0, -1.0])
-out.update(overlap_minres_rel=d.norm() / w2.norm(), it4=it4, it2=it2)
+out.update(overlap_minres_rel=d.norm() / w2.norm(), it4=it4, it2=it2, coll=w2.last_solve_stats["collectives"])
+import ctypes
+buf = ctypes.create_string_buffer(512)
+ea._lib.call("hipeig_comm_library", buf, 512)
+out["rccl"] = buf.value.decode()
+out["torch_loaded"] = "torch" in sys.modules
 print("RESULT " + json.dumps(out))
 """
 
@@ -69,3 +74,7 @@ def test_forced_collectives_single_rank():
     assert r["cumIter"] == int(g["cumIter"]) and r["conv"]
     assert r["overlap_spmv_rel"] < 1e-14
     assert r["it4"] == r["it2"] and r["overlap_minres_rel"] < 1e-8
+    enq = 16 * -(-r["it2"] // 16)
+    assert r["coll"] == 2 * enq + enq // 16                  # one all-gather + one fused all-reduce per iteration
+    # the collectives run on ROCm's own RCCL, whatever else the process has loaded; no torch on the product path
+    assert r["rccl"].startswith("/opt/rocm") and not r["torch_loaded"], r["rccl"]

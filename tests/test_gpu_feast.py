@@ -70,3 +70,72 @@ def test_feast_reference_problem_on_device(hip):
     for e in inside:
         vec = Yf[hip.find_nearest(ev, e)[0]].array
         assert abs(abs(np.vdot(V[:, hip.find_nearest(w, e)[0]], vec)) - 1) < 1e-2
+
+
+# ---------------------------------------------------------------- complex128 input vectors (numpyVector.py:89-93)
+def test_complex_vectors_match_the_ndarray_backend(hip, gapped4000):
+    """``HipVector(complex array)`` gives a complex device vector (two real halves) with the semantics of a
+    complex-dtype NumpyVector: conjugated ``vdot`` / bilinear ``vdot(conjugate=False)``, complex scalars and
+    coefficients, Hermitian Gram builders, the bilinear Gram-Schmidt sweep incl. its ``None`` exit, and the
+    solves (real shift + MINRES: the two halves in lock step; complex shift + GCROT).  Checked against
+    ``oracle.numpy_vector.RefVector`` (the restatement of NumpyVector) on the same complex data."""
+    from oracle.numpy_vector import RefVector
+    Hh, _ = gapped4000
+    H = hip.HipCsrOperator.from_scipy(Hh)
+    rng = np.random.default_rng(23)
+    n = 4000
+    zs = [rng.standard_normal(n) + 0.3j * rng.standard_normal(n) for _ in range(5)]     # Re(x.x) > 0: the bilinear sweep keeps them
+    opts = lambda: {"linearSystemArgs": {"linearSolver": "minres", "linearIter": 2000, "linear_tol": 1e-10}}
+    D = [hip.HipVector(z.copy(), opts()) for z in zs]
+    R = [RefVector(z.copy(), opts()) for z in zs]
+    assert all(type(d) is hip.HipComplexVector and d.dtype == np.complex128 and len(d) == n for d in D)
+    assert issubclass(hip.HipComplexVector, hip.AbstractVector) and not hip.HipComplexVector.__abstractmethods__
+    scale = float(np.sum(np.abs(zs[0] * zs[1])))
+    for conj in (True, False):
+        assert abs(D[0].vdot(D[1], conjugate=conj) - R[0].vdot(R[1], conjugate=conj)) <= 1e-13 * scale
+    xr = hip.HipVector(zs[2].real.copy())                                # mixed: complex against a real device vector
+    assert abs(D[0].vdot(xr) - np.vdot(zs[0], zs[2].real)) <= 1e-13 * scale
+    assert abs(D[0].norm() - R[0].norm()) <= 1e-14 * R[0].norm()
+    np.testing.assert_allclose((D[0] * (0.3 - 1.7j)).array, (R[0] * (0.3 - 1.7j)).array, rtol=1e-15, atol=1e-15)
+    np.testing.assert_allclose(((2 + 1j) * D[0]).array, ((2 + 1j) * R[0]).array, rtol=1e-15, atol=1e-15)
+    np.testing.assert_allclose((D[0] / (1.5 + 0.5j)).array, (R[0] / (1.5 + 0.5j)).array, rtol=4e-16, atol=1e-15)
+    np.testing.assert_array_equal(D[0].real().array, zs[0].real)
+    np.testing.assert_array_equal(D[0].conjugate().array, zs[0].conj())
+    np.testing.assert_array_equal(D[0].copy().array, zs[0])
+    with pytest.raises(NotImplementedError):
+        D[0] *= 2.0
+    c = D[1].copy().normalize()
+    np.testing.assert_allclose(c.array, zs[1] / np.linalg.norm(zs[1]), rtol=2e-15, atol=1e-18)
+    ay = D[0].applyOp(H).array
+    ref = Hh @ zs[0]
+    assert np.max(np.abs(ay - ref)) <= 1e-13 * np.max(np.abs(ref))
+    coeffs = [0.5 + 1j, -1.25, 2.0j, 0.125 - 0.5j, -3.0]
+    np.testing.assert_allclose(hip.HipComplexVector.linearCombination(D, coeffs).array,
+                               RefVector.linearCombination(R, coeffs).array, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(hip.HipComplexVector.overlapMatrix(D), RefVector.overlapMatrix(R), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(hip.HipComplexVector.matrixRepresentation(H, D), RefVector.matrixRepresentation(Hh, R), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(hip.HipComplexVector.extendOverlapMatrix(D, hip.HipComplexVector.overlapMatrix(D[:4])),
+                               RefVector.extendOverlapMatrix(R, RefVector.overlapMatrix(R[:4])), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(hip.HipComplexVector.extendMatrixRepresentation(H, D, hip.HipComplexVector.matrixRepresentation(H, D[:4])),
+                               RefVector.extendMatrixRepresentation(Hh, R, RefVector.matrixRepresentation(Hh, R[:4])), rtol=0, atol=1e-10)
+    # the reference's Gram-Schmidt sweep with its bilinear products, incl. the lindep -> None exit
+    o_d = hip.HipComplexVector.orthogonalize_against_set(D[4], D[:3])
+    o_r = RefVector.orthogonalize_against_set(R[4], R[:3])
+    assert o_r is not None and o_d is not None
+    np.testing.assert_allclose(o_d.array, o_r.array, rtol=0, atol=1e-12)
+    dep = 0.3 * zs[0] - (0.2 + 1j) * zs[1]
+    assert hip.HipComplexVector.orthogonalize_against_set(hip.HipVector(dep.copy(), opts()), D[:2]) is None
+    assert RefVector.orthogonalize_against_set(RefVector(dep.copy(), opts()), R[:2]) is None
+    # solves: (sigma - H) x = b with complex b
+    b = zs[3] / np.linalg.norm(zs[3])
+    exact = np.linalg.solve(0.02 * np.eye(n) - Hh.toarray(), b)
+    w = hip.HipComplexVector.solve(H, hip.HipVector(b.copy(), opts()), 0.02)
+    assert type(w) is hip.HipComplexVector
+    assert np.linalg.norm(w.array - exact) <= 1e-7 * np.linalg.norm(exact)
+    og = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 2000, "linear_tol": 1e-9, "linear_atol": 1e-12}}
+    z = 0.05 + 0.3j
+    wz = hip.HipComplexVector.solve(H, hip.HipVector(b.copy(), og), z)
+    exact_z = np.linalg.solve(z * np.eye(n) - Hh.toarray(), b)
+    assert np.linalg.norm(wz.array - exact_z) <= 1e-7 * np.linalg.norm(exact_z)
+    wz_ref = RefVector.solve(Hh, RefVector(b.copy(), og), z)
+    assert np.linalg.norm(wz.array - wz_ref.array) <= 1e-7 * np.linalg.norm(exact_z)

@@ -98,6 +98,7 @@ def test_split_sweep_and_minres_with_two_ranks(hip, csplit, monkeypatch):
             out[f"spmv{variant}"] = float(np.max(np.abs(y - y_ref[b:e])) / np.max(np.abs(y_ref)))
             w = hip.HipVector.solve(H, hip.HipVector(b_full[b:e].copy(), dict(OPTS), ctx=ctx), 0.02)
             out[f"it{variant}"] = w.last_solve_stats["iterations"]
+            out[f"coll{variant}"] = w.last_solve_stats["collectives"]
             out[f"w{variant}"] = w.array
         return out
 
@@ -109,6 +110,11 @@ def test_split_sweep_and_minres_with_two_ranks(hip, csplit, monkeypatch):
         for o in res:
             assert o[f"spmv{variant}"] < 1e-14
             assert abs(o[f"it{variant}"] - it_ref) <= 2
+            assert o[f"it{variant}"] == res[0][f"it{variant}"]                 # identical decisions on every rank
+            # per iteration ONE operand all-gather and ONE fused all-reduce (<v,y>, <y,y>, lagged <x,x>);
+            # iterations are enqueued in chunks of 16 and each chunk ends with one small all-reduce for the stop check
+            enq = 16 * -(-o[f"it{variant}"] // 16)
+            assert o[f"coll{variant}"] == 2 * enq + enq // 16, (o[f"coll{variant}"], enq)
         w = np.concatenate([o[f"w{variant}"] for o in res])
         assert np.linalg.norm(w - w_ref) <= 1e-8 * np.linalg.norm(w_ref)
 
@@ -186,3 +192,92 @@ def test_eight_ranks_wide_operator(hip):
         assert err < 1e-14
         assert dot == res[0][2] and abs(dot - np.dot(x, x)) < 1e-10 * np.dot(x, x)
         assert its == 60
+
+
+def test_block_product_and_block_solve_on_two_ranks(hip, monkeypatch):
+    """The block path on a row partition: the interleaved operand block is all-gathered (one collective
+    for all 8 columns), both block kernels run on remapped columns, and the lock-step MINRES takes the
+    same decisions on both ranks and returns the single-GPU solutions."""
+    N, P, k = 120_000, 2, 5
+    single = hip.HipCsrOperator.generate(N, 32, seed=5)
+    rng = np.random.default_rng(8)
+    Xh = rng.standard_normal((N, k))
+    Bh = Xh / np.linalg.norm(Xh, axis=0)
+    ref = [hip.HipVector(Xh[:, j].copy()).applyOp(single).array for j in range(k)]
+    opts = {"linearSystemArgs": {"linearSolver": "minres", "linearIter": 2000, "linear_tol": 1e-8}}
+    sols = hip.HipVector.solveBlock(single, [hip.HipVector(Bh[:, j].copy(), dict(opts)) for j in range(k)], 0.02)
+    its_ref = [w.last_solve_stats["iterations"] for w in sols]
+    sols = [w.array for w in sols]
+    grp = LoopbackGroup(P)
+
+    def body(rank, ctx):
+        b, e = row_range(N, P, rank)
+        H = hip.HipCsrOperator.generate(N, 32, seed=5, row_begin=b, row_end=e, ctx=ctx)
+        out = {}
+        for bv in (1, 2):
+            H.set_block_variant(bv)
+            Y = H.apply_block([hip.HipVector(Xh[b:e, j].copy(), ctx=ctx)._buf for j in range(k)])
+            out[f"y{bv}"] = [hip.HipVector(y).array for y in Y]
+            W = hip.HipVector.solveBlock(H, [hip.HipVector(Bh[b:e, j].copy(), dict(opts), ctx=ctx) for j in range(k)], 0.02)
+            out[f"w{bv}"] = [w.array for w in W]
+            out[f"it{bv}"] = [w.last_solve_stats["iterations"] for w in W]
+            out[f"kind{bv}"] = H.block_info()["variant"]
+        return out, (b, e)
+
+    try:
+        res = grp.run(body)
+    finally:
+        grp.close()
+    for bv, kind in ((1, "row-owner"), (2, "column-window-blocked")):
+        assert all(o[f"kind{bv}"] == kind for o, _ in res)
+        assert res[0][0][f"it{bv}"] == res[1][0][f"it{bv}"]
+        for j in range(k):
+            y = np.concatenate([o[f"y{bv}"][j] for o, _ in res])
+            assert np.max(np.abs(y - ref[j])) <= 1e-13 * np.max(np.abs(ref[j]))
+            w = np.concatenate([o[f"w{bv}"][j] for o, _ in res])
+            assert np.linalg.norm(w - sols[j]) <= 1e-6 * np.linalg.norm(sols[j])
+            assert abs(res[0][0][f"it{bv}"][j] - its_ref[j]) <= 2
+
+
+def test_config4_operator_on_eight_ranks(hip):
+    """BASELINE config #4 shape on one GPU: the N = 1e7, 64 nnz/row operator row-partitioned over 8
+    loopback ranks (each builds its own 1.25e6-row slab on the device), a few products and shifted
+    products against the whole operator held by a ninth context, and 20 MINRES iterations with the
+    fused reductions.  Size-independent checks only (no oracle at this size)."""
+    N, P = 10_000_000, 8
+    whole = hip.HipCsrOperator.generate(N, 64, seed=7)
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal(N)
+    y_ref = hip.HipVector(x).applyOp(whole).array
+    scale = np.max(np.abs(y_ref))
+    nnz_whole = whole.nnz
+    del whole
+    opts = {"linearSystemArgs": {"linearSolver": "minres", "linearIter": 20, "linear_tol": 1e-30}}
+    grp = LoopbackGroup(P)
+
+    def body(rank, ctx):
+        b, e = row_range(N, P, rank)
+        H = hip.HipCsrOperator.generate(N, 64, seed=7, row_begin=b, row_end=e, ctx=ctx)
+        X = hip.HipVector(x[b:e], ctx=ctx)
+        y = X.applyOp(H)
+        err = float(np.max(np.abs(y.array - y_ref[b:e])))
+        buf = ctx.alloc(e - b)
+        H.apply_shifted(0.02, X._buf, buf)
+        errs = float(np.max(np.abs(hip.HipVector(buf).array - (0.02 * x[b:e] - y_ref[b:e]))))
+        sym = X.vdot(y)                                    # <x, Hx>, all-reduced
+        try:
+            hip.HipVector.solve(H, hip.HipVector(x[b:e] / np.linalg.norm(x), dict(opts), ctx=ctx), 0.02)
+            its = -1
+        except UserWarning:
+            its = 20
+        return err, errs, sym, its, H.nnz, H.last_variant()
+
+    try:
+        res = grp.run(body)
+    finally:
+        grp.close()
+    assert sum(r[4] for r in res) == nnz_whole
+    for err, errs, sym, its, nnz, variant in res:
+        assert err <= 1e-13 * scale and errs <= 1e-13 * scale
+        assert sym == res[0][2] and abs(sym - np.dot(x, y_ref)) <= 1e-10 * abs(np.dot(x, y_ref)) + 1e-6
+        assert its == 20 and variant == "column-window-blocked(workgroup)"
