@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--nnz-row", type=int, default=64)
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--sigma", type=float, default=0.02)
-    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 CSR-vector, 2 CSR-stream, 3/4 column-window blocked (wave / workgroup units)")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 CSR-vector, 2 CSR-stream, 3/4 column-window blocked (wave / workgroup units), 5 = 4 with fixed-point accumulators (reproducible)")
     ap.add_argument("--no-lanczos", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-block", action="store_true", help="skip the block-of-8 solve timing (BASELINE config #3, N = 1e6)")
@@ -116,7 +116,8 @@ def main(result):
     # HBM traffic per launch from the committed PMC pass (cannot be collected inside this process)
     traffic, kname = None, {"csr-vector": "spmv_vector_kernel", "csr-stream": "spmv_stream_kernel",
                             "column-window-blocked(wave)": "spmv_tcoo_kernel",
-                            "column-window-blocked(workgroup)": "spmv_tcoow_kernel"}[H.last_variant()]
+                            "column-window-blocked(workgroup)": "spmv_tcoow_kernel",
+                            "column-window-blocked(workgroup, fixed-point)": "spmv_tcoow_kernel"}[H.last_variant()]
     try:
         pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_current.json")))
         if pmc["config"] == {"N": N, "nnz_row": a.nnz_row, "n_gpus": world}:

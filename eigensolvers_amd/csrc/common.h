@@ -113,6 +113,7 @@ struct hipeig_csr {
   uint32_t* w_off;
   int32_t w_nunits, w_nwin, w_wbits, w_rw, w_wgs_per_sweep;
   int32_t w_csplit;          // workgroups sharing one row block (column splits), 1 = none
+  double absrow_max;         // max_i sum_j |a_ij| over the local rows: overflow bound of the fixed-point sweep (variant 5)
   // block-operand copy ("TCOO-B", spmm_device.h): units sized for 8 accumulators per row; built on first use
   uint32_t* b_idx;
   double* b_val;
@@ -122,7 +123,7 @@ struct hipeig_csr {
   int32_t block_variant;     // 0 = automatic, 1 = row-owner CSR, 2 = TCOO-B
   int32_t last_block_variant;
   int64_t gather_len;        // length of the gathered operand (ncols, or stride*nranks)
-  int variant;               // 0 = auto, 1 = CSR-vector, 2 = CSR-stream, 3 = TCOO (wave units), 4 = TCOO-W
+  int variant;               // 0 = auto, 1 = CSR-vector, 2 = CSR-stream, 3 = TCOO (wave units), 4 = TCOO-W, 5 = TCOO-W with fixed-point accumulators
   int last_variant;          // variant used by the most recent launch (0 = none yet)
   int last_launches;         // kernel launches (sweeps) one product with that variant takes
   int lanes_per_row;         // sub-wave width used to reduce one row

@@ -22,6 +22,7 @@ size_t hipeig_tcoow_lds_bytes(const hipeig_csr* A);
 int hipeig_tcoow_prepare(hipeig_ctx* c, hipeig_csr* A, const double* x_local, TcooView* tv, const double** xg, int* ncombine);
 int64_t hipeig_tcoow_part_stride(const hipeig_csr* A);
 int hipeig_tcoow_reserve(hipeig_ctx* c, const hipeig_csr* A);
+int hipeig_fixed_prepare(hipeig_ctx* c, const hipeig_csr* A, const double* xg, TcooView* t);
 int hipeig_spmv_grid(const hipeig_csr* A, int variant);
 int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A);
 size_t hipeig_tcoo_lds_bytes(const hipeig_csr* A);
@@ -53,7 +54,8 @@ struct MinresRowEpilogue {
 // written, in partials[b] and partials[HIPEIG_MAX_PARTIALS + b]; beta_{k+1}^2 = <y - alfa v, y - alfa v>
 // = <y,y> - alfa^2 then needs no second reduction (v is a unit vector), and the stopping tests of the
 // previous iteration move to the next kernel, where <x,x> arrives with the same all-reduce.
-template <int VARIANT, int FUSED = 0>
+// FIXED = 1 (VARIANT 4 only): fixed-point accumulators, public kernel variant 5 (spmv_device.h).
+template <int VARIANT, int FUSED = 0, int FIXED = 0>
 __global__ void __launch_bounds__(VARIANT == 4 ? TCOOW_THREADS : HIPEIG_BLOCK)
 minres_ka_kernel(CsrView A, TcooView T, const double* __restrict__ xg, MinresArgs a, const MinresState* __restrict__ Sin,
                  MinresState* __restrict__ Sout, const double* __restrict__ r2l,
@@ -76,7 +78,7 @@ minres_ka_kernel(CsrView A, TcooView T, const double* __restrict__ xg, MinresArg
   double acc = 0.0, acc_yy = 0.0;
   epi.yy = FUSED ? &acc_yy : nullptr;
   if (VARIANT == 5) tcoow_combine_sweep(T.raw_out, T.part_base, T.part_stride, T.nrows, epi, acc);
-  else if (VARIANT == 4) tcoo_wg_sweep(T, xg, epi, acc, tcoo_lds);
+  else if (VARIANT == 4) tcoo_wg_sweep<MinresRowEpilogue, FIXED>(T, xg, epi, acc, tcoo_lds, red);
   else if (VARIANT == 3) tcoo_sweep(T, xg, epi, acc, tcoo_lds);
   else if (VARIANT == 2) csr_stream_sweep(A, xg, epi, acc, prod);
   else csr_vector_sweep(A, xg, epi, acc);
@@ -270,14 +272,19 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   // the pinned record is rewritten by the first chunk's copy-back; the upload above must have read it
   HIPEIG_CHECK(hipStreamSynchronize(c->stream));
 
-  const int variant = hipeig_csr_pick_variant(c, A);
+  int variant = hipeig_csr_pick_variant(c, A);
   if (variant < 0) return 1;
+  const bool fixed = (variant == 5);                    // TCOO-W with fixed-point accumulators: same structure as 4
+  if (fixed) variant = 4;
   if (variant == 4 && hipeig_tcoow_reserve(c, A)) return 1;
   const CsrView view = hipeig_csr_view(A);
   const TcooView tview = (variant == 4) ? hipeig_tcoow_view(A) : hipeig_tcoo_view(A);
-  if (variant == 4)
-    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)HIPEIG_TCOOW_LDS_MAX));
+  if (variant == 4) {
+    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<4, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIPEIG_TCOOW_LDS_MAX));
+    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<4, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIPEIG_TCOOW_LDS_MAX));
+    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<4, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIPEIG_TCOOW_LDS_MAX));
+    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<4, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIPEIG_TCOOW_LDS_MAX));
+  }
   if (variant == 3)
     HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)HIPEIG_TCOO_LDS_MAX));
@@ -318,9 +325,15 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
       int ncombine = 0;                                           // local windows under the all-gather
       if (hipeig_tcoow_prepare(c, A, r2, &tv, &xg, &ncombine)) return 4;
       if (c->collectives) ++c->mr_collectives;                    // the operand all-gather
+      if (fixed && hipeig_fixed_prepare(c, A, xg, &tv)) return 4;
       for (int sw = 0; sw < nsweepA; ++sw) {
         tv.unit_begin = sw * gA;
-        KA_LAUNCH(4, gA, TCOOW_THREADS, hipeig_tcoow_lds_bytes(A), tv, pA + sw * gA);
+        if (fixed) {
+          if (fused) hipLaunchKernelGGL((minres_ka_kernel<4, 1, 1>), dim3(gA), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, view, tv, xg, a, V + 0, V + 1, r2, r1, yb, pA + sw * gA);
+          else hipLaunchKernelGGL((minres_ka_kernel<4, 0, 1>), dim3(gA), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, view, tv, xg, a, V + 0, V + 1, r2, r1, yb, pA + sw * gA);
+        } else {
+          KA_LAUNCH(4, gA, TCOOW_THREADS, hipeig_tcoow_lds_bytes(A), tv, pA + sw * gA);
+        }
       }
       if (ncombine) {
         TcooView tc = tv;
@@ -408,7 +421,7 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
     key.n = n; key.nnz = A->nnz; key.variant = variant; key.gA = gA; key.nsweep = nsweepA;
     key.units = (variant == 4) ? A->w_nunits : (variant == 3) ? A->t_nunits : A->n_row_blocks;
     key.lds = (variant == 4) ? (int64_t)hipeig_tcoow_lds_bytes(A) : (variant == 3) ? (int64_t)hipeig_tcoo_lds_bytes(A) : 0;
-    key.csplit = (variant == 4) ? A->w_csplit : 0;
+    key.csplit = (variant == 4) ? A->w_csplit + (fixed ? 1000 : 0) : 0;
     key.maxiter = maxiter; key.sigma = sigma; key.sign = sign; key.rtol = rtol;
     const int gchunk = 18;
     if (!c->mr_graph || c->mr_graph_key_bytes != sizeof(key) || memcmp(c->mr_graph_key, &key, sizeof(key)) != 0) {

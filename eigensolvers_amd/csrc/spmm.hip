@@ -120,6 +120,9 @@ BcooView hipeig_bcoo_view(const hipeig_csr* A) {
 // (idempotent).  Returns 2 (TCOO-B) or 1 (row-owner), -1 on failure.
 int hipeig_block_pick_variant(hipeig_ctx* c, hipeig_csr* A) {
   if (A->block_variant == 1 || A->nnz == 0 || A->nrows == 0) return A->last_block_variant = 1;
+  // an operator pinned to a reproducible kernel (variants 1-3, 5) keeps that promise for block products and block
+  // solves too: the row-owner kernel adds a row's terms in a fixed order, the window-blocked one uses fp64 atomics
+  if (A->block_variant == 0 && A->variant != 0 && A->variant != 4) return A->last_block_variant = 1;
   if (A->b_state == 1) return A->last_block_variant = 2;
   if (A->b_state == 2 && A->block_variant == 0) return A->last_block_variant = 1;
   int wbits = 11;                                        // 2 Ki columns x 64 B = 128 KiB of X per window (measured best of 8..15 at N = 1e6: 32 windows fit one L2, so workgroups that drift apart still hit)

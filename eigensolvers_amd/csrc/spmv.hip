@@ -40,11 +40,54 @@ spmv_tcoo_kernel(TcooView T, const double* __restrict__ x, AxpyEpilogue epi) {
   tcoo_sweep(T, x, epi, acc, tcoo_lds);
 }
 
+template <int FIXED>
 __global__ void __launch_bounds__(TCOOW_THREADS)
 spmv_tcoow_kernel(TcooView T, const double* __restrict__ x, AxpyEpilogue epi) {
   extern __shared__ double tcoo_lds[];
+  __shared__ double red16[16];
   double acc = 0.0;
-  tcoo_wg_sweep(T, x, epi, acc, tcoo_lds);
+  tcoo_wg_sweep<AxpyEpilogue, FIXED>(T, x, epi, acc, tcoo_lds, red16);
+}
+
+__global__ void __launch_bounds__(HIPEIG_BLOCK) absmax_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ partials) {
+  __shared__ double lds[16];
+  double m = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double v = fabs(x[i]);
+    m = (v > m || v != v) ? v : m;                     // NaN sticks
+  }
+  m = block_max_all(m, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = m;
+}
+
+// max_i sum_j |a_ij| over the local rows (one wavefront per row), as per-workgroup maxima
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+rowabs_max_kernel(const int32_t* __restrict__ rowptr, const double* __restrict__ val, int64_t nrows, double* __restrict__ partials) {
+  __shared__ double lds[16];
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  double m = 0.0;
+  for (int64_t r = wave; r < nrows; r += nwaves) {
+    double a = 0.0;
+    for (int p = rowptr[r] + lane; p < rowptr[r + 1]; p += 64) a += fabs(val[p]);
+    a = wave_reduce_sum(a);
+    a = __shfl(a, 0, 64);
+    m = fmax(m, a);
+  }
+  m = block_max_all(m, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = m;
+}
+
+// Operand maximum for the fixed-point sweep: per-workgroup maxima into the context's fx area.
+#define HIPEIG_FX_AREA (8 * HIPEIG_MAX_PARTIALS)
+int hipeig_fixed_prepare(hipeig_ctx* c, const hipeig_csr* A, const double* xg, TcooView* t) {
+  const int g = grid_for(A->gather_len, 8);
+  double* area = c->d_partials + HIPEIG_FX_AREA;
+  hipLaunchKernelGGL(absmax_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, xg, A->gather_len, area);
+  t->fx_xmax = area; t->fx_count = g; t->fx_bound = A->absrow_max;
+  return 0;
 }
 
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
@@ -65,6 +108,7 @@ TcooView hipeig_tcoow_view(const hipeig_csr* A) {
   t.gather_len = A->gather_len;
   t.win_lo = 0; t.win_hi = A->w_nwin; t.invert = 0; t.yinit = nullptr; t.raw_out = nullptr;
   t.csplit = 1; t.part_base = 0; t.part_stride = 0;
+  t.fx_xmax = nullptr; t.fx_count = 0; t.fx_bound = 0.0;
   return t;
 }
 
@@ -80,6 +124,7 @@ TcooView hipeig_tcoo_view(const hipeig_csr* A) {
   t.gather_len = A->gather_len;
   t.win_lo = 0; t.win_hi = A->t_nwin; t.invert = 0; t.yinit = nullptr; t.raw_out = nullptr;
   t.csplit = 1; t.part_base = 0; t.part_stride = 0;
+  t.fx_xmax = nullptr; t.fx_count = 0; t.fx_bound = 0.0;
   return t;
 }
 
@@ -149,7 +194,7 @@ int hipeig_tcoow_reserve(hipeig_ctx* c, const hipeig_csr* A) {
 // store raw slabs and the caller combines them.  Returns 1 when the split path was taken (tv2 / xg
 // set), 0 when the caller should use the plain all-gather + full sweep, -1 on error.
 int hipeig_tcoow_overlap_begin(hipeig_ctx* c, hipeig_csr* A, const double* x_local, TcooView* tv2, const double** xg) {
-  if (!c->collectives || !c->overlap || !A->w_idx || A->col_stride <= 0) return 0;
+  if (!c->collectives || !c->overlap || !A->w_idx || A->col_stride <= 0 || A->last_variant == 5) return 0;   // the fixed-point form needs max|x| of the whole operand first
   const int64_t lo = (int64_t)c->rank * A->col_stride, hi = lo + A->nrows;
   const int64_t W = (int64_t)1 << A->w_wbits;
   const int cl0 = (int)((lo + W - 1) >> A->w_wbits), cl1 = (int)(hi >> A->w_wbits);
@@ -166,7 +211,7 @@ int hipeig_tcoow_overlap_begin(hipeig_ctx* c, hipeig_csr* A, const double* x_loc
   for (int ub = 0; ub < A->w_nunits * cs; ub += g) {
     t.unit_begin = ub;
     // x_local - lo: global column j of the local range is x_local[j - lo]
-    hipLaunchKernelGGL(spmv_tcoow_kernel, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t, x_local - lo, none);
+    hipLaunchKernelGGL(spmv_tcoow_kernel<0>, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t, x_local - lo, none);
   }
   if (hipGetLastError() != hipSuccess) { hipeig_set_error("local-window launch failed"); return -1; }
   if (hipeig_allgather_x_end(c, xg)) return -1;
@@ -200,20 +245,24 @@ int hipeig_tcoow_prepare(hipeig_ctx* c, hipeig_csr* A, const double* x_local, Tc
 static int launch_spmv(hipeig_ctx* c, hipeig_csr* A, double a_self, double a_sum,
                        const double* x, double* y) {
   if (A->nrows == 0) return 0;
-  const int variant = hipeig_csr_pick_variant(c, A);
+  int variant = hipeig_csr_pick_variant(c, A);
   if (variant < 0) return 1;
   // shift term: x restricted to this operator's rows.  Partitioned run: x IS that slice; a row
   // slab applied to a full-length operand (single process): the slice starts at row_offset.
   AxpyEpilogue epi{a_self, a_sum, c->collectives ? x : x + A->row_offset, y};
   const double* xg = nullptr;
+  const bool fixed = (variant == 5);                 // TCOO-W with fixed-point accumulators
+  if (fixed) variant = 4;
   const int g = hipeig_spmv_grid(A, variant);
   if (variant == 4) {
     TcooView t;
     int ncombine = 0;
     if (hipeig_tcoow_prepare(c, A, x, &t, &xg, &ncombine)) return 4;
+    if (fixed && hipeig_fixed_prepare(c, A, xg, &t)) return 4;
     for (int ub = 0; ub < A->w_nunits * t.csplit; ub += g) {           // one launch per sweep
       t.unit_begin = ub;
-      hipLaunchKernelGGL(spmv_tcoow_kernel, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t, xg, epi);
+      if (fixed) hipLaunchKernelGGL(spmv_tcoow_kernel<1>, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t, xg, epi);
+      else hipLaunchKernelGGL(spmv_tcoow_kernel<0>, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t, xg, epi);
     }
     if (ncombine)
       hipLaunchKernelGGL(spmv_tcoow_combine_kernel, dim3(grid_for(A->nrows, 2)), dim3(HIPEIG_BLOCK), 0, c->stream,
@@ -494,8 +543,22 @@ int hipeig_csr_build_tcoow(hipeig_ctx* c, hipeig_csr* A) {
   if (per_cu > 2) per_cu = 2;                          // 1024-thread workgroups: at most 32 waves per CU
   if (per_cu < 1) per_cu = 1;
   A->w_wgs_per_sweep = per_cu * c->num_cu;
-  HIPEIG_CHECK(hipFuncSetAttribute((const void*)spmv_tcoow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+  HIPEIG_CHECK(hipFuncSetAttribute((const void*)spmv_tcoow_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)HIPEIG_TCOOW_LDS_MAX));
+  HIPEIG_CHECK(hipFuncSetAttribute((const void*)spmv_tcoow_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)HIPEIG_TCOOW_LDS_MAX));
+  {
+    // bound of the fixed-point form (variant 5): max_i sum_j |a_ij| over the local rows
+    const int gr = 8 * c->num_cu < HIPEIG_MAX_PARTIALS ? 8 * c->num_cu : HIPEIG_MAX_PARTIALS;
+    double* area = c->d_partials + HIPEIG_FX_AREA;
+    hipLaunchKernelGGL(rowabs_max_kernel, dim3(gr), dim3(HIPEIG_BLOCK), 0, c->stream, A->d_rowptr, A->d_val, A->nrows, area);
+    std::vector<double> part((size_t)gr);
+    HIPEIG_CHECK(hipMemcpyAsync(part.data(), area, sizeof(double) * gr, hipMemcpyDeviceToHost, c->stream));
+    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+    double m = 0.0;
+    for (double v : part) m = (v > m || v != v) ? v : m;
+    A->absrow_max = m;
+  }
   A->bytes += (int64_t)A->nnz * 12 + (int64_t)(ntile + 1) * 4;
   return 0;
 }
@@ -507,7 +570,7 @@ int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A) {
     // the gathered operand does not fit one XCD's L2 -> window it; small problems stream
     variant = (A->gather_len * 8 > (int64_t)3 << 20 && A->nnz > (int64_t)1 << 20) ? 4 : 2;
   }
-  if (variant == 4) {
+  if (variant == 4 || variant == 5) {
     const int rc = hipeig_csr_build_tcoow(c, A);
     if (rc == 1) return -1;
     if (rc == 2) variant = 3;
@@ -519,7 +582,7 @@ int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A) {
   }
   A->last_variant = variant;
   A->last_launches = 1;
-  if (variant == 4) {
+  if (variant == 4 || variant == 5) {
     int g = A->w_wgs_per_sweep < A->w_nunits ? A->w_wgs_per_sweep : A->w_nunits;
     A->last_launches = (A->w_csplit > 1) ? 1 : (A->w_nunits + g - 1) / g;     // sweep launches (split mode adds a combine launch)
   } else if (variant == 3) {
@@ -662,8 +725,21 @@ extern "C" int hipeig_csr_info(hipeig_csr* A, int64_t info[8]) {
   return 0;
 }
 
+// Error-bound ingredients of the fixed-point variant: out[0] = max_i sum_j |a_ij| (local rows, set when the
+// blocked layout is built; 0 before), out[1] = max |x| of the operand of the most recent variant-5 product.
+extern "C" int hipeig_csr_fixed_info(hipeig_ctx* c, hipeig_csr* A, double out[2]) {
+  out[0] = A->absrow_max;
+  out[1] = 0.0;
+  const int g = grid_for(A->gather_len, 8);
+  std::vector<double> part((size_t)g);
+  HIPEIG_CHECK(hipMemcpyAsync(part.data(), c->d_partials + HIPEIG_FX_AREA, sizeof(double) * g, hipMemcpyDeviceToHost, c->stream));
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  for (double v : part) out[1] = (v > out[1] || v != v) ? v : out[1];
+  return 0;
+}
+
 extern "C" int hipeig_csr_set_variant(hipeig_csr* A, int variant) {
-  HIPEIG_REQUIRE(variant >= 0 && variant <= 4, "unknown variant");
+  HIPEIG_REQUIRE(variant >= 0 && variant <= 5, "unknown variant");
   A->variant = variant;
   return 0;
 }

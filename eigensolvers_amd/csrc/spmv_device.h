@@ -161,6 +161,15 @@ struct TcooView {
   // to raw_out + (part_base + s) * part_stride; a combine kernel adds the slabs and runs the epilogue.
   int32_t csplit, part_base;
   int64_t part_stride;
+  // fixed-point accumulation (TCOO-W, public variant 5): the accumulators are int64 sums of
+  // rint(v*x*2^e); e is chosen in the kernel prologue from fx_bound = max_i sum_j |a_ij| (set when the
+  // layout is built) and max|x| (fx_count per-workgroup maxima left by absmax_kernel in fx_xmax), so that no
+  // row can overflow 2^62.  Integer adds commute: the result does not depend on the order in which waves
+  // reach a row nor on the slot order of the layout build - bitwise reproducible, at the speed of the
+  // atomic-fp64 form.  Absolute error per row <= (nnz_row/2 + 1) * 2^-61 * fx_bound * max|x|.
+  const double* fx_xmax;
+  int32_t fx_count;
+  double fx_bound;
 };
 
 __device__ __forceinline__ void lds_add_f64(double* p, double v) {
@@ -299,9 +308,41 @@ __device__ __forceinline__ void tcoow_combine_sweep(const double* __restrict__ p
   }
 }
 
-template <class Epi>
+// max over the workgroup of per-thread values (exact, order-free); every thread obtains it.  lds: 16 doubles.
+__device__ __forceinline__ double block_max_all(double v, double* lds) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) lds[wid] = v;
+  __syncthreads();
+  double r = lds[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = fmax(r, lds[w]);
+  __syncthreads();
+  return r;
+}
+
+// 2^e with bound * xmax * 2^e < 2^62 (one bit of headroom below int64 for the rounding of the terms).
+// A non-finite operand gives NaN, which the epilogue's multiplication by 1/scale spreads over the result.
+__device__ __forceinline__ double fixed_point_scale(double bound, double xmax) {
+  const double v = bound * xmax;
+  if (!(v > 0.0)) return (v == 0.0) ? 1.0 : __builtin_nan("");
+  if (!(v < 1.7976931348623157e308)) return __builtin_nan("");
+  int ex;
+  frexp(v, &ex);                                   // v < 2^ex
+  int e = 61 - ex;
+  e = e > 1000 ? 1000 : (e < -1000 ? -1000 : e);
+  return ldexp(1.0, e);
+}
+
+__device__ __forceinline__ void lds_add_i64_wg(double* slot, double scaled) {
+  __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double2ll_rn(scaled),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <class Epi, int FIXED = 0>
 __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* __restrict__ x, const Epi& epi,
-                                              double& acc, double* yacc /* rw doubles + (nwin+1) uint32 of LDS */) {
+                                              double& acc, double* yacc /* rw doubles + (nwin+1) uint32 of LDS */,
+                                              double* red16 = nullptr /* FIXED: 16 doubles of LDS */) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nw = blockDim.x >> 6;
   const uint32_t cmask = (1u << T.wbits) - 1u;
@@ -311,8 +352,19 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
   if (u >= T.nunits) return;                         // uniform for the workgroup
   uint32_t* offL = reinterpret_cast<uint32_t*>(yacc + T.rw);     // this unit's window offsets
   const int64_t r0 = (int64_t)u * T.rw;
-  for (int k = threadIdx.x; k < T.rw; k += blockDim.x)
-    yacc[k] = (T.yinit && r0 + k < T.nrows) ? T.yinit[r0 + k] : 0.0;
+  double fx_scale = 1.0, fx_inv = 1.0;
+  if (FIXED) {
+    double m = 0.0;
+    for (int k = threadIdx.x; k < T.fx_count; k += blockDim.x) m = fmax(m, T.fx_xmax[k]);
+    m = block_max_all(m, red16);
+    fx_scale = fixed_point_scale(T.fx_bound, m);
+    fx_inv = 1.0 / fx_scale;                         // exact: a power of two
+  }
+  for (int k = threadIdx.x; k < T.rw; k += blockDim.x) {
+    const double y0 = (T.yinit && r0 + k < T.nrows) ? T.yinit[r0 + k] : 0.0;
+    if (FIXED) reinterpret_cast<long long*>(yacc)[k] = __double2ll_rn(y0 * fx_scale);
+    else yacc[k] = y0;
+  }
   for (int k = threadIdx.x; k <= T.nwin; k += blockDim.x) offL[k] = T.off[(size_t)u * T.nwin + k];
   __syncthreads();
   // The unit's non-zeros are ONE contiguous stream (window after window).  Waves take
@@ -356,7 +408,10 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
     }                                                                                  \
     if (!(TCOO_ABL(T, 2))) {                                                             \
       _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j)                          \
-        if (ID[j] != 0xFFFFFFFFu) lds_add_f64_wg(yacc + (ID[j] >> T.wbits), V[j]);     \
+        if (ID[j] != 0xFFFFFFFFu) {                                                    \
+          if (FIXED) lds_add_i64_wg(yacc + (ID[j] >> T.wbits), V[j] * fx_scale);       \
+          else lds_add_f64_wg(yacc + (ID[j] >> T.wbits), V[j]);                        \
+        }                                                                              \
     } else {                                                                           \
       _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j) sink += V[j] + (double)ID[j]; \
     }                                                                                  \
@@ -397,8 +452,13 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
   __syncthreads();
   if (T.raw_out) {
     double* dst = T.raw_out + (int64_t)(T.part_base + cs) * T.part_stride;
-    for (int k = threadIdx.x; k < T.rw && r0 + k < T.nrows; k += blockDim.x) dst[r0 + k] = yacc[k];
+    for (int k = threadIdx.x; k < T.rw && r0 + k < T.nrows; k += blockDim.x)
+      dst[r0 + k] = FIXED ? (double)reinterpret_cast<const long long*>(yacc)[k] * fx_inv : yacc[k];
   } else {
-    for (int k = threadIdx.x; k < T.rw && r0 + k < T.nrows; k += blockDim.x) epi.row(r0 + k, yacc[k], acc);
+    for (int k = threadIdx.x; k < T.rw && r0 + k < T.nrows; k += blockDim.x)
+      epi.row(r0 + k, FIXED ? (double)reinterpret_cast<const long long*>(yacc)[k] * fx_inv : yacc[k], acc);
   }
 }
+
+// per-workgroup max |x_i| -> partials[blockIdx.x] (operand of the fixed-point sweep)
+__global__ void __launch_bounds__(HIPEIG_BLOCK) absmax_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ partials);

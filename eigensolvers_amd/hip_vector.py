@@ -196,10 +196,22 @@ class HipCsrOperator:
         return cls(ctx, h)
 
     VARIANTS = {0: "none", 1: "csr-vector", 2: "csr-stream", 3: "column-window-blocked(wave)",
-                4: "column-window-blocked(workgroup)"}
+                4: "column-window-blocked(workgroup)", 5: "column-window-blocked(workgroup, fixed-point)"}
 
     def set_variant(self, variant):
+        """Operator kernel: 0 automatic; 1 CSR-vector, 2 CSR-stream, 3 column-window blocked with wave-owned rows
+        (these three fix the order of the adds inside a row: bitwise reproducible); 4 column-window blocked with
+        workgroup-owned rows and fp64 LDS atomics (the fast default for large operators; a row's sum is
+        reproducible to rounding only); 5 the same sweep with FIXED-POINT accumulators - integer adds commute, so
+        it is bitwise reproducible at the speed of 4, with an absolute error per row of
+        ~nnz_row * 2^-61 * max_i sum_j|a_ij| * max|x| instead of fp64's relative one."""
         _lib.call("hipeig_csr_set_variant", self.handle, int(variant))
+
+    def fixed_point_info(self):
+        """(max_i sum_j |a_ij|, max |x| of the last variant-5 operand): what bounds variant 5's absolute error."""
+        out = (C.c_double * 2)()
+        _lib.call("hipeig_csr_fixed_info", self.ctx.handle, self.handle, out)
+        return float(out[0]), float(out[1])
 
     def last_variant(self):
         """Name of the kernel variant the most recent product used."""

@@ -160,8 +160,13 @@ int hipeig_csr_info(hipeig_csr* A, int64_t info[8]);
 /* copy the device CSR (local rows) back to the host; pass NULL to skip an array          */
 int hipeig_csr_download(hipeig_ctx* ctx, hipeig_csr* A, int64_t* rowptr, int32_t* col,
                         double* val);
-/* force a kernel variant (0 = automatic choice, 1..4 as above); for benchmarking/ablation */
+/* force a kernel variant (0 = automatic choice, 1..4 as above, 5 = variant 4 with fixed-point (int64) LDS
+ * accumulators: bitwise reproducible whatever the order in which waves reach a row, same speed; absolute error per
+ * row ~ nnz_row * 2^-61 * max_i sum_j|a_ij| * max|x|) */
 int hipeig_csr_set_variant(hipeig_csr* A, int variant);
+/* variant 5's error-bound ingredients: out[0] = max_i sum_j |a_ij| over the local rows, out[1] = max |x| of the
+ * operand of the most recent variant-5 product; absolute error per row <= (nnz_row/2 + 1) * 2^-60 * out[0] * out[1] */
+int hipeig_csr_fixed_info(hipeig_ctx* ctx, hipeig_csr* A, double out[2]);
 
 /* applyOp, numpyVector.py:98-100: y = H x.  x,y are local slices.                        */
 int hipeig_spmv(hipeig_ctx* ctx, hipeig_csr* A, const double* x, double* y);

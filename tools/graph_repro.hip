@@ -3,7 +3,7 @@
 // what hipeig_minres captures - a chain of kernels with > 64 KiB of dynamic LDS and 1024-thread
 // workgroups plus small 256-thread kernels, thread-local capture mode, an optional device-to-pinned-host
 // copy node - with nothing of the library in it, so that a crash here is the tool's and not ours.
-//   graph_repro [copy=0|1] [lds_kb=0..158] [mode=0 global|1 threadlocal|2 relaxed] [iters]
+//   graph_repro [copy=0|1] [lds_kb=0..158] [mode=0 global|1 threadlocal|2 relaxed] [iters] [replays]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -27,6 +27,7 @@ int main(int argc, char** argv) {
   const int lds_kb = argc > 2 ? atoi(argv[2]) : 158;
   const int mode = argc > 3 ? atoi(argv[3]) : 1;
   const int iters = argc > 4 ? atoi(argv[4]) : 18;
+  const int replays = argc > 5 ? atoi(argv[5]) : 20;
   const int n = 1 << 20;
   hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   double *x, *rec, *hrec;
@@ -46,13 +47,14 @@ int main(int argc, char** argv) {
   CK(hipStreamEndCapture(s, &g));
   CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
   CK(hipGraphDestroy(g));
-  for (int r = 0; r < 20; ++r) {
+  for (int r = 0; r < replays; ++r) {
     CK(hipGraphLaunch(ge, s));
     CK(hipStreamSynchronize(s));
+    if ((r + 1) % 50 == 0) { fprintf(stderr, "replay %d done\n", r + 1); fflush(stderr); }
   }
   if (!copy) CK(hipMemcpy(hrec, rec, 64, hipMemcpyDeviceToHost));
-  printf("graph_repro copy=%d lds_kb=%d mode=%d iters=%d: ok, record %.0f (expected %d)\n", copy, lds_kb, mode, iters, hrec[0],
-         copy ? 20 * 2 * iters : 20 * 2 * iters);
+  printf("graph_repro copy=%d lds_kb=%d mode=%d iters=%d replays=%d: ok, record %.0f (expected %d)\n", copy, lds_kb, mode, iters, replays,
+         hrec[0], replays * 2 * iters);
   CK(hipGraphExecDestroy(ge));
   return 0;
 }
