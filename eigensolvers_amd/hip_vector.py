@@ -206,6 +206,20 @@ class HipCsrOperator:
         it is bitwise reproducible at the speed of 4, with an absolute error per row of
         ~nnz_row * 2^-61 * max_i sum_j|a_ij| * max|x| instead of fp64's relative one."""
         _lib.call("hipeig_csr_set_variant", self.handle, int(variant))
+        self._variant = int(variant)
+
+    def honour_reduction_option(self, options):
+        """``options["reduction"]`` of the vectors: "deterministic" makes an operator that is
+        on the automatic / fast kernel use the fixed-point one (variant 5, bitwise reproducible at the same speed),
+        "fast" puts it back on the automatic choice.  An explicitly pinned variant 1-3 is left alone."""
+        want = (options or {}).get("reduction")
+        cur = getattr(self, "_variant", 0)
+        if want == "deterministic" and cur in (0, 4):
+            self.set_variant(5)
+        elif want == "fast" and cur == 5:
+            self.set_variant(0)
+        elif want not in (None, "deterministic", "fast"):
+            raise ValueError(f'options["reduction"] must be "deterministic" or "fast", got {want!r}')
 
     def fixed_point_info(self):
         """(max_i sum_j |a_ij|, max |x| of the last variant-5 operand): what bounds variant 5's absolute error."""
@@ -307,7 +321,7 @@ class HipVector(AbstractVector):
         lsa.setdefault("linear_tol", 1e-4)
         lsa.setdefault("linear_atol", 1e-4)
         self.options = {"linearSystemArgs": lsa}
-        for extra in ("orthogonalization", "blockSolve"):
+        for extra in ("orthogonalization", "blockSolve", "reduction"):
             if extra in given:
                 self.options[extra] = given[extra]
         self.last_solve_stats = None
@@ -407,6 +421,7 @@ class HipVector(AbstractVector):
     def applyOp(self, other):
         if not isinstance(other, HipCsrOperator):
             raise TypeError("HipVector.applyOp needs a HipCsrOperator (device-resident CSR)")
+        other.honour_reduction_option(self.options)
         out = self.ctx.alloc(other.nrows)
         other.apply(self._buf, out)
         return self._new(out)
@@ -463,6 +478,7 @@ class HipVector(AbstractVector):
             raise TypeError("HipVector.solve needs a HipCsrOperator (device-resident CSR)")
         if x0 is not None:
             raise NotImplementedError("HipVector.solve starts from a zero guess (the Lanczos path passes none)")
+        H.honour_reduction_option(b.options)
         o = b.options["linearSystemArgs"]
         name = o["linearSolver"]
         if isinstance(sigma, complex) or np.iscomplexobj(sigma):
@@ -519,6 +535,7 @@ class HipVector(AbstractVector):
         if (o["linearSolver"] != "minres" or isinstance(sigma, complex) or np.iscomplexobj(sigma)
                 or x0 is not None or len(bs) == 1 or not isinstance(H, HipCsrOperator)):
             return [HipVector.solve(H, b, sigma, x0, opType, reverseGF) for b in bs]
+        H.honour_reduction_option(bs[0].options)
         ctx, n = bs[0].ctx, bs[0]._buf.n
         results = []
         for i0 in range(0, len(bs), 8):
@@ -603,6 +620,7 @@ class HipVector(AbstractVector):
             raise TypeError("HipVector.matrixRepresentation needs a HipCsrOperator (device-resident CSR)")
         m = len(vectors)
         v0 = vectors[0]
+        operator.honour_reduction_option(v0.options)
         # all kets H y_j in one block product, then one Gram block <y_i, H y_j> on the matrix cores
         kets = operator.apply_block([v._buf for v in vectors])
         M = np.empty((m, m), dtype=np.float64)

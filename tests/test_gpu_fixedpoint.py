@@ -147,3 +147,25 @@ def test_checkpoint_resume_is_bit_for_bit_with_the_fixed_point_kernel(hip, tmp_p
     np.testing.assert_array_equal(ev2, ev)
     np.testing.assert_array_equal(Y2[0].array, Y[0].array)
     assert st2["cumIter"] == st["cumIter"] and st2["residual"] == st["residual"]
+
+
+def test_reduction_option_selects_the_reproducible_kernel(hip):
+    """``options["reduction"] = "deterministic" | "fast"`` on the vectors."""
+    from eigensolvers_amd.generators import guess_vector
+    N = 300_000
+    H = hip.HipCsrOperator.generate(N, 32, seed=5)
+    g = guess_vector(N, 2)
+    runs = []
+    for _ in range(2):
+        o = _opts(); o["reduction"] = "deterministic"
+        ev, Y, st = hip.inexactLanczosDiagonalization(H, hip.HipVector(g.copy(), o), 0.02, 5, 4, 1e-12, writeOut=False)
+        assert H.last_variant() == "column-window-blocked(workgroup, fixed-point)"
+        runs.append((ev, Y[0].array))
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    o = _opts(); o["reduction"] = "fast"
+    hip.HipVector(g.copy(), o).applyOp(H)
+    assert H.last_variant() == "column-window-blocked(workgroup)"
+    with pytest.raises(ValueError):
+        bad = _opts(); bad["reduction"] = "sloppy"
+        hip.HipVector(g.copy(), bad).applyOp(H)

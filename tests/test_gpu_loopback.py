@@ -281,3 +281,24 @@ def test_config4_operator_on_eight_ranks(hip):
         assert err <= 1e-13 * scale and errs <= 1e-13 * scale
         assert sym == res[0][2] and abs(sym - np.dot(x, y_ref)) <= 1e-10 * abs(np.dot(x, y_ref)) + 1e-6
         assert its == 20 and variant == "column-window-blocked(workgroup)"
+
+
+def test_device_group_scalars_on_loopback_ranks(hip):
+    """bench.py's barrier / max-over-ranks / sum-over-ranks (distributed.DeviceGroup: the library's own all-reduce,
+    no torch) with three ranks."""
+    from eigensolvers_amd.distributed import DeviceGroup
+    grp = LoopbackGroup(3)
+
+    def body(rank, ctx):
+        g = DeviceGroup(ctx)
+        g.barrier()
+        out = (g.allgather_scalar(rank + 0.5), g.allmax(10.0 * rank), g.allsum(rank + 1.0), g.rank, g.world)
+        g.barrier()
+        return out
+
+    try:
+        res = grp.run(body)
+    finally:
+        grp.close()
+    for r, (gathered, mx, sm, rank, world) in enumerate(res):
+        assert gathered == [0.5, 1.5, 2.5] and mx == 20.0 and sm == 6.0 and (rank, world) == (r, 3)

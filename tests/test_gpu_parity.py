@@ -387,6 +387,10 @@ def test_lanczos_checkpoint_resume_and_thick_restart_on_device(hip, gapped4000, 
     d = str(tmp_path / "ck")
     ev, Y, st = run(checkpointDir=d, checkpointKeep=0)
     assert st["isConverged"] and st["cumIter"] > 5
+    # not only self-consistent: the CPU restatement of the reference loop at the same parameters (L = 5, no golden
+    # file covers them) gives the same Ritz value, iteration count and exit
+    evo, Yo, sto = lanczos_ref.inexact_lanczos(Hh, RefVector(guess.copy(), _opts()), 0.02, 5, 6, 1e-12)
+    assert abs(ev[0] - evo[0]) <= 1e-10 * abs(evo[0]) and st["cumIter"] == sto["cumIter"] and sto["isConverged"]
     for it in (2, 4, 5):
         ev2, Y2, st2 = run(resumeFrom=f"{d}/krylov_{it:06d}.npz")
         np.testing.assert_array_equal(ev2, ev)

@@ -8,10 +8,11 @@ as parity / behaviour cases with timings:
       GPU, Ritz value compared with the known spectrum (the CPU-oracle comparison of this case lives in
       tests/test_gpu_parity.py - the oracle is test infrastructure and is not imported here).
   #2  random-sparse CSR N = 1e6, 33 nnz/row, single-vector Lanczos to convergence (MINRES 1e-10).
-  #3  the same operator, block Lanczos with 8 orthonormal guesses (one restart cycle).
-  #5  FEAST: window [-0.21, 0.21] around the 16 clustered eigenvalues, m0 = 20, nc = 8 (4 complex
-      contour solves per vector), GCROT - at N = 2e4 so that a run takes a minute (the complex solves
-      are host-orchestrated pair arithmetic for now).
+  #3  the same operator, block Lanczos with 8 orthonormal guesses run to convergence: once with the
+      lock-step block solves (default) and once with one-by-one solves (options["blockSolve"] = False).
+  #5  FEAST: window [-0.21, 0.21] around the 16 clustered eigenvalues, m0 = 16, nc = 16 (8 half-contour
+      solves per vector), GCROT - at N = 2e4 by default (FEAST_N); tools/experiments/feast_profile_run.py
+      is the N = 1e6 run.
 
 usage: python tools/bench_configs.py [out.json]
 """
@@ -67,31 +68,39 @@ def config2_3():
           "lanczos_iters_per_s": round(st["cumIter"] / t, 3), "minres_iters_last_solve": Y[0].last_solve_stats and Y[0].last_solve_stats["iterations"],
           "kernel": H.last_variant()}
     Q8 = la.qr(np.random.default_rng(5).standard_normal((N, 8)), mode="economic")[0]
-    v8 = [ea.HipVector(Q8[:, i].copy(), opt(1e-8)) for i in range(8)]
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        (evb, Yb, stb), tb = timed(lambda: ea.inexactLanczosDiagonalization(H, v8, 0.02, 3, 1, 1e-7, writeOut=False))
-    c3 = {"N": N, "nBlock": 8, "L": 3, "cumIter": stb["cumIter"], "basis": len(Yb), "seconds": round(tb, 3),
-          "solves": 8 * stb["cumIter"], "solves_per_s": round(8 * stb["cumIter"] / tb, 3),
-          "lowest_block_values": [float(v) for v in np.sort(evb[:8])] if not np.any(np.isnan(evb)) else None,
-          "lindep_exit": bool(np.any(np.isnan(evb)))}
+    c3 = {"N": N, "nBlock": 8, "L": 12, "maxit": 2, "linear_tol": 1e-11, "eConv": 1e-12}
+    for tag, flag in (("lock_step_block_solves", True), ("one_by_one_solves", False)):
+        o8 = lambda: dict(opt(1e-11), blockSolve=flag)
+        v8 = [ea.HipVector(Q8[:, i].copy(), o8()) for i in range(8)]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            (evb, Yb, stb), tb = timed(lambda: ea.inexactLanczosDiagonalization(H, v8, 0.02, 12, 2, 1e-12, writeOut=False))
+        ok = not np.any(np.isnan(evb))
+        c3[tag] = {"cumIter": stb["cumIter"], "converged": bool(stb["isConverged"]), "basis": len(Yb), "seconds": round(tb, 3),
+                   "solves": 8 * stb["cumIter"], "solves_per_s": round(8 * stb["cumIter"] / tb, 3),
+                   "lanczos_iters_per_s": round(stb["cumIter"] / tb, 3),
+                   "block_values": [float(v) for v in np.sort(evb[:8])] if ok else None,
+                   "true_residual_norms": [float(r) for r in ea.true_residual_norms(H, evb, Yb, 8)] if ok else None,
+                   "block_kernel": H.block_info()["variant"]}
+    c3["speedup_lock_step"] = round(c3["one_by_one_solves"]["seconds"] / c3["lock_step_block_solves"]["seconds"], 3)
+    c3["target_value_vs_single_vector_rel"] = abs(min(c3["lock_step_block_solves"]["block_values"], key=lambda v: abs(v - c2["ritz"])) - c2["ritz"]) / abs(c2["ritz"])
     return c2, c3
 
 
 def config5():
-    N, m0 = int(os.environ.get("FEAST_N", 20_000)), int(os.environ.get("FEAST_M0", 18))
+    N, m0 = int(os.environ.get("FEAST_N", 20_000)), int(os.environ.get("FEAST_M0", 16))
     H = ea.HipCsrOperator.generate(N, 32, seed=7)
     Y0 = la.qr(np.random.default_rng(9).standard_normal((N, m0)), mode="economic")[0]
-    opt = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 2000, "linear_tol": 1e-4, "linear_atol": 1e-12}}
+    opt = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 2000, "linear_tol": 1e-5, "linear_atol": 1e-7}}
     Y = [ea.HipVector(Y0[:, i].copy(), opt) for i in range(m0)]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        (ev, Yf, st), t = timed(lambda: ea.feastDiagonalization(H, Y, int(os.environ.get("FEAST_NC", 8)), "legendre", -0.21, 0.21, 1e-9,
-                                                                int(os.environ.get("FEAST_MAXIT", 4)), writeOut=True,
+        (ev, Yf, st), t = timed(lambda: ea.feastDiagonalization(H, Y, int(os.environ.get("FEAST_NC", 16)), "legendre", -0.21, 0.21, 1e-4,
+                                                                int(os.environ.get("FEAST_MAXIT", 12)), writeOut=True,
                                                                 summaryFileName=os.path.join(REPO, "gpurun_out", "feast_summary.out")))
     inside = np.sort(ev[(ev >= -0.21) & (ev <= 0.21)])
     res = ea.true_residual_norms(H, ev, Yf)
-    return {"N": N, "m0": m0, "contour_points": int(os.environ.get("FEAST_NC", 8)) // 2, "outerIter": st["outerIter"], "residual": st["residual"],
+    return {"N": N, "m0": m0, "contour_points": int(os.environ.get("FEAST_NC", 16)) // 2, "outerIter": st["outerIter"], "residual": st["residual"],
             "eigenvalues_in_window": [float(v) for v in inside], "count_in_window": int(len(inside)),
             "max_true_residual_in_window": float(max(r for e, r in zip(ev, res) if -0.21 <= e <= 0.21)),
             "seconds": round(t, 3)}
