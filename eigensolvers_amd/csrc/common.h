@@ -114,14 +114,16 @@ struct hipeig_csr {
   int32_t w_nunits, w_nwin, w_wbits, w_rw, w_wgs_per_sweep;
   int32_t w_csplit;          // workgroups sharing one row block (column splits), 1 = none
   double absrow_max;         // max_i sum_j |a_ij| over the local rows: overflow bound of the fixed-point sweep (variant 5)
-  // block-operand copy ("TCOO-B", spmm_device.h): units sized for 8 accumulators per row; built on first use
-  uint32_t* b_idx;
-  double* b_val;
-  uint32_t* b_off;
-  int32_t b_nunits, b_nwin, b_wbits, b_rw, b_wgs_per_sweep;
-  int32_t b_state;           // 0 = undecided, 1 = built, 2 = not suited (row-owner kernel is used)
+  // block-operand copies ("TCOO-B", spmm_device.h): one per interleave width, [0]: K = 4, [1]: K = 8; built on first use
+  struct BcooLayout {
+    uint32_t* idx;
+    double* val;
+    uint32_t* off;
+    int32_t nunits, nwin, wbits, rw, wgs_per_sweep;
+    int32_t state;           // 0 = undecided, 1 = built, 2 = not suited (row-owner kernel is used)
+  } bl[2];
   int32_t block_variant;     // 0 = automatic, 1 = row-owner CSR, 2 = TCOO-B
-  int32_t last_block_variant;
+  int32_t last_block_variant, last_block_k;
   int64_t gather_len;        // length of the gathered operand (ncols, or stride*nranks)
   int variant;               // 0 = auto, 1 = CSR-vector, 2 = CSR-stream, 3 = TCOO (wave units), 4 = TCOO-W, 5 = TCOO-W with fixed-point accumulators
   int last_variant;          // variant used by the most recent launch (0 = none yet)

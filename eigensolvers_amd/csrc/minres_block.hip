@@ -15,23 +15,26 @@
 #include "minres_device.h"
 #include "spmm_device.h"
 
-int hipeig_block_pick_variant(hipeig_ctx* c, hipeig_csr* A);
-BcooView hipeig_bcoo_view(const hipeig_csr* A);
-size_t hipeig_bcoo_lds_bytes(const hipeig_csr* A);
-int hipeig_block_allgather(hipeig_ctx* c, hipeig_csr* A, const double* xb_local, const double** xb_full);
-int hipeig_block_pack(hipeig_ctx* c, int64_t n, int k, const double* const* cols, double* blk);
-int hipeig_block_unpack(hipeig_ctx* c, int64_t n, int k, const double* blk, double* const* cols);
+int hipeig_block_pick_variant(hipeig_ctx* c, hipeig_csr* A, int K);
+BcooView hipeig_bcoo_view(const hipeig_csr* A, int K);
+size_t hipeig_bcoo_lds_bytes(const hipeig_csr* A, int K);
+int hipeig_bcoo_grid(const hipeig_csr* A, int K);
+int hipeig_block_allgather(hipeig_ctx* c, hipeig_csr* A, int K, const double* xb_local, const double** xb_full);
+int hipeig_block_pack(hipeig_ctx* c, int K, int64_t n, int k, const double* const* cols, double* blk);
+int hipeig_block_unpack(hipeig_ctx* c, int K, int64_t n, int k, const double* blk, double* const* cols);
 int hipeig_rowowner_grid(const hipeig_ctx* c, const hipeig_csr* A);
 
-#define MRB_PART_STRIDE (HIPEIG_MAX_PARTIALS * BCOO_K)     // doubles between the three partial areas
+#define MRB_PART_STRIDE (HIPEIG_MAX_PARTIALS * BCOO_KMAX)     // doubles between the three partial areas
 
-// Per-operand sum of `count` partial records for the operand threadIdx.x % 8 (count == 1: the record
+// Per-operand sum of `count` partial records for the operand threadIdx.x % K (count == 1: the record
 // has already been reduced, e.g. by an all-reduce).
-__device__ __forceinline__ double sum_or_value_cols8(const double* p, int count, double* lds) {
-  if (count == 1) return p[threadIdx.x & 7];
-  return block_sum_partials_cols8(p, count, lds);
+template <int K>
+__device__ __forceinline__ double sum_or_value_cols(const double* p, int count, double* lds) {
+  if (count == 1) return p[threadIdx.x % K];
+  return block_sum_partials_cols<K>(p, count, lds);
 }
 
+template <int K>
 struct MinresBlockEpilogue {
   double sigma, sign, s, c1;         // s, c1: the scalars of THIS thread's operand (threadIdx.x % 8)
   int use_r1;
@@ -39,7 +42,7 @@ struct MinresBlockEpilogue {
   const double* __restrict__ r1;
   double* __restrict__ y;
   __device__ __forceinline__ void elem(int64_t r, int j, double sum, double& acc) const {
-    const int64_t i = r * BCOO_K + j;
+    const int64_t i = r * K + j;
     const double v = s * r2l[i];
     double yv = sign * (mul_rn(sigma, v) - s * sum);
     if (use_r1) yv -= c1 * r1[i];
@@ -49,21 +52,21 @@ struct MinresBlockEpilogue {
 };
 
 // VARIANT 2: window-blocked (TCOO-B) sweep, 1024 threads; VARIANT 1: row-owner CSR sweep, 256 threads.
-template <int VARIANT>
+template <int VARIANT, int K>
 __global__ void __launch_bounds__(VARIANT == 2 ? BCOO_THREADS : HIPEIG_BLOCK)
 minres_block_ka_kernel(BcooView T, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                        const double* __restrict__ val, int64_t nrows, const double* __restrict__ xg, MinresArgs a,
                        const MinresState* __restrict__ Sin, MinresState* __restrict__ Sout,
                        const double* __restrict__ r2l, const double* __restrict__ r1, double* __restrict__ y,
                        double* __restrict__ partials) {
-  __shared__ double red[(VARIANT == 2 ? BCOO_THREADS : HIPEIG_BLOCK) / 64 * 8];
-  __shared__ double sh_s[8], sh_c1[8];
-  __shared__ int sh_use[8], sh_live;
+  __shared__ double red[(VARIANT == 2 ? BCOO_THREADS : HIPEIG_BLOCK) / 64 * K];
+  __shared__ double sh_s[K], sh_c1[K];
+  __shared__ int sh_use[K], sh_live;
   extern __shared__ double bcoo_lds[];
-  const double xx = sum_or_value_cols8(a.pD, a.nD, red);
+  const double xx = sum_or_value_cols<K>(a.pD, a.nD, red);
   if (threadIdx.x == 0) sh_live = 0;
   __syncthreads();
-  if (threadIdx.x < 8) {
+  if (threadIdx.x < K) {
     MinresState S = Sin[threadIdx.x];
     minres_tests(S, (S.itn > 0 && !S.done) ? xx : 0.0, a);
     if (blockIdx.x == 0) Sout[threadIdx.x] = S;
@@ -75,73 +78,76 @@ minres_block_ka_kernel(BcooView T, const int32_t* __restrict__ rowptr, const int
   }
   __syncthreads();
   if (!sh_live) return;                                   // every column has stopped
-  MinresBlockEpilogue epi;
-  const int j = threadIdx.x & 7;
+  MinresBlockEpilogue<K> epi;
+  const int j = threadIdx.x % K;
   epi.sigma = a.sigma; epi.sign = a.sign; epi.s = sh_s[j]; epi.c1 = sh_c1[j]; epi.use_r1 = sh_use[j];
   epi.r2l = r2l; epi.r1 = r1; epi.y = y;
   double acc = 0.0;
-  if (VARIANT == 2) bcoo_wg_sweep(T, xg, epi, acc, bcoo_lds);
-  else csr_rowowner_block_sweep(rowptr, col, val, nrows, xg, epi, acc);
-  const double tot = block_reduce_cols8(acc, red);
-  if (threadIdx.x < 8) partials[(size_t)blockIdx.x * BCOO_K + threadIdx.x] = tot;
+  if (VARIANT == 2) bcoo_wg_sweep<K>(T, xg, epi, acc, bcoo_lds);
+  else csr_rowowner_block_sweep<K>(rowptr, col, val, nrows, xg, epi, acc);
+  const double tot = block_reduce_cols<K>(acc, red);
+  if (threadIdx.x < K) partials[(size_t)blockIdx.x * K + threadIdx.x] = tot;
 }
 
-// Fold (a0, a1) - partials of operands 2(t%4) and 2(t%4)+1 - over the workgroup; record in threads 0..7.
+// Fold (a0, a1) - partials of operands 2(t % (K/2)) and the next - over the workgroup; record in threads 0..K-1.
+template <int K>
 __device__ __forceinline__ void block_reduce_pairs(double a0, double a1, double* lds, double* __restrict__ out_record) {
 #pragma unroll
-  for (int off = 4; off < 64; off <<= 1) {
+  for (int off = K / 2; off < 64; off <<= 1) {
     a0 += __shfl_xor(a0, off, 64);
     a1 += __shfl_xor(a1, off, 64);
   }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (lane < 4) { lds[wid * 8 + lane * 2] = a0; lds[wid * 8 + lane * 2 + 1] = a1; }
+  if (lane < K / 2) { lds[wid * K + lane * 2] = a0; lds[wid * K + lane * 2 + 1] = a1; }
   __syncthreads();
-  if (threadIdx.x < 8) {
+  if (threadIdx.x < K) {
     double r = lds[threadIdx.x];
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r += lds[w * 8 + threadIdx.x];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r += lds[w * K + threadIdx.x];
     out_record[threadIdx.x] = r;
   }
 }
 
+template <int K>
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
 minres_block_kc_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, MinresState* __restrict__ Sout,
                        const double* __restrict__ r2, double* __restrict__ y, double* __restrict__ partials) {
-  __shared__ double red[HIPEIG_BLOCK / 64 * 8];
-  __shared__ double sh_c[8];
-  const double alfa = sum_or_value_cols8(a.pA, a.nA, red);
-  if (threadIdx.x < 8) {
+  __shared__ double red[HIPEIG_BLOCK / 64 * K];
+  __shared__ double sh_c[K];
+  const double alfa = sum_or_value_cols<K>(a.pA, a.nA, red);
+  if (threadIdx.x < K) {
     MinresState S = Sin[threadIdx.x];
     if (!S.done) S.alfa = alfa;
     if (blockIdx.x == 0) Sout[threadIdx.x] = S;
     sh_c[threadIdx.x] = S.done ? 0.0 : S.alfa / S.beta;
   }
   __syncthreads();
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;           // multiple of 4: operand pair fixed per thread
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;           // multiple of K/2: operand pair fixed per thread
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int j0 = (int)(t0 & 3) * 2;
+  const int j0 = (int)(t0 % (K / 2)) * 2;
   const double c0 = sh_c[j0], c1 = sh_c[j0 + 1];
   const double2* r22 = reinterpret_cast<const double2*>(r2);
   double2* y2 = reinterpret_cast<double2*>(y);
   double a0 = 0.0, a1 = 0.0;
-  for (int64_t t = t0; t < n * 4; t += stride) {
+  for (int64_t t = t0; t < n * (K / 2); t += stride) {
     const double2 rv = r22[t];
     double2 yv = y2[t];
     yv.x -= c0 * rv.x; yv.y -= c1 * rv.y;
     y2[t] = yv;
     a0 = fma(yv.x, yv.x, a0); a1 = fma(yv.y, yv.y, a1);
   }
-  block_reduce_pairs(a0, a1, red, partials + (size_t)blockIdx.x * BCOO_K);
+  block_reduce_pairs<K>(a0, a1, red, partials + (size_t)blockIdx.x * K);
 }
 
+template <int K>
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
 minres_block_kd_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, MinresState* __restrict__ Sout,
                        const double* __restrict__ r2old, const double* __restrict__ w1, const double* __restrict__ w2,
                        double* __restrict__ w, double* __restrict__ x, double* __restrict__ partials) {
-  __shared__ double red[HIPEIG_BLOCK / 64 * 8];
-  __shared__ double sh_sold[8], sh_oldeps[8], sh_delta[8], sh_denom[8], sh_phi[8];
-  __shared__ int sh_done[8];
-  const double bb = sum_or_value_cols8(a.pC, a.nC, red);
-  if (threadIdx.x < 8) {
+  __shared__ double red[HIPEIG_BLOCK / 64 * K];
+  __shared__ double sh_sold[K], sh_oldeps[K], sh_delta[K], sh_denom[K], sh_phi[K];
+  __shared__ int sh_done[K];
+  const double bb = sum_or_value_cols<K>(a.pC, a.nC, red);
+  if (threadIdx.x < K) {
     MinresState S = Sin[threadIdx.x];
     sh_sold[threadIdx.x] = S.s;
     if (!S.done) minres_advance(S, bb);
@@ -153,7 +159,7 @@ minres_block_kd_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ 
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int j0 = (int)(t0 & 3) * 2, j1 = j0 + 1;
+  const int j0 = (int)(t0 % (K / 2)) * 2, j1 = j0 + 1;
   const double s0 = sh_sold[j0], e0 = sh_oldeps[j0], d0 = sh_delta[j0], q0 = sh_denom[j0], p0 = sh_phi[j0];
   const double s1 = sh_sold[j1], e1 = sh_oldeps[j1], d1 = sh_delta[j1], q1 = sh_denom[j1], p1 = sh_phi[j1];
   const bool live0 = !sh_done[j0], live1 = !sh_done[j1];
@@ -164,7 +170,7 @@ minres_block_kd_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ 
   double2* x2 = reinterpret_cast<double2*>(x);
   double a0 = 0.0, a1 = 0.0;
   if (live0 || live1) {
-    for (int64_t t = t0; t < n * 4; t += stride) {
+    for (int64_t t = t0; t < n * (K / 2); t += stride) {
       const double2 rv = r2[t], b1 = w12[t], b2 = w22[t];
       double2 xv = x2[t], wn;
       // a stopped column keeps its iterate; its w is never read again, so what is stored there is irrelevant
@@ -177,15 +183,16 @@ minres_block_kd_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ 
       a0 = fma(xv.x, xv.x, a0); a1 = fma(xv.y, xv.y, a1);
     }
   }
-  block_reduce_pairs(a0, a1, red, partials + (size_t)blockIdx.x * BCOO_K);
+  block_reduce_pairs<K>(a0, a1, red, partials + (size_t)blockIdx.x * K);
 }
 
 // End-of-chunk evaluation of the stopping tests (what KA's prologue would do next).
+template <int K>
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
 minres_block_check_kernel(MinresArgs a, MinresState* __restrict__ S0) {
-  __shared__ double red[HIPEIG_BLOCK / 64 * 8];
-  const double xx = sum_or_value_cols8(a.pD, a.nD, red);
-  if (threadIdx.x < 8) {
+  __shared__ double red[HIPEIG_BLOCK / 64 * K];
+  const double xx = sum_or_value_cols<K>(a.pD, a.nD, red);
+  if (threadIdx.x < K) {
     MinresState S = S0[threadIdx.x];
     minres_tests(S, (S.itn > 0 && !S.done) ? xx : 0.0, a);
     S0[threadIdx.x] = S;
@@ -193,18 +200,20 @@ minres_block_check_kernel(MinresArgs a, MinresState* __restrict__ S0) {
 }
 
 // one record of 8 per-operand sums from `count` partial records (distributed path, before the all-reduce)
+template <int K>
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
-sum_partials_cols8_kernel(const double* __restrict__ p, int count, double* __restrict__ out) {
-  __shared__ double red[HIPEIG_BLOCK / 64 * 8];
-  const double v = block_sum_partials_cols8(p, count, red);
-  if (threadIdx.x < 8) out[threadIdx.x] = v;
+sum_partials_cols_kernel(const double* __restrict__ p, int count, double* __restrict__ out) {
+  __shared__ double red[HIPEIG_BLOCK / 64 * K];
+  const double v = block_sum_partials_cols<K>(p, count, red);
+  if (threadIdx.x < K) out[threadIdx.x] = v;
 }
 
-extern "C" int hipeig_minres_block(hipeig_ctx* c, hipeig_csr* A, double sigma, double sign, int k,
-                                   const double* const* b, double* const* x, double rtol, int maxiter,
-                                   int* info, double* out_stats) {
+template <int K>
+static int minres_block_impl(hipeig_ctx* c, hipeig_csr* A, double sigma, double sign, int k,
+                             const double* const* b, double* const* x, double rtol, int maxiter,
+                             int* info, double* out_stats) {
   HIPEIG_REQUIRE(info != nullptr && b != nullptr && x != nullptr, "null argument");
-  HIPEIG_REQUIRE(k >= 1 && k <= BCOO_K, "a block solve takes 1..8 right-hand sides");
+  HIPEIG_REQUIRE(k >= 1 && k <= K, "more right-hand sides than the interleave width");
   HIPEIG_REQUIRE(sign == 1.0 || sign == -1.0, "sign must be +1 or -1");
   HIPEIG_REQUIRE(maxiter >= 1, "maxiter must be positive");
   HIPEIG_REQUIRE(c->collectives || A->nrows == A->ncols, "the inner solve needs a square operator (or a row partition)");
@@ -218,12 +227,12 @@ extern "C" int hipeig_minres_block(hipeig_ctx* c, hipeig_csr* A, double sigma, d
 
   // recurrence records: <b_j, b_j> with the same reduction as the single-vector driver
   if (!c->d_mrb_state) {
-    HIPEIG_CHECK(hipMalloc((void**)&c->d_mrb_state, 3 * BCOO_K * sizeof(MinresState)));
-    HIPEIG_CHECK(hipHostMalloc((void**)&c->h_mrb_state, BCOO_K * sizeof(MinresState), hipHostMallocDefault));
+    HIPEIG_CHECK(hipMalloc((void**)&c->d_mrb_state, 3 * BCOO_KMAX * sizeof(MinresState)));
+    HIPEIG_CHECK(hipHostMalloc((void**)&c->h_mrb_state, BCOO_KMAX * sizeof(MinresState), hipHostMallocDefault));
   }
   MinresState* h = c->h_mrb_state;
   int live = 0;
-  for (int j = 0; j < BCOO_K; ++j) {
+  for (int j = 0; j < K; ++j) {
     double bb = 0.0;
     if (j < k && hipeig_dot(c, n, b[j], b[j], &bb)) return 1;
     if (bb > 0.0) { minres_init_state(&h[j], bb); ++live; }
@@ -238,7 +247,7 @@ extern "C" int hipeig_minres_block(hipeig_ctx* c, hipeig_csr* A, double sigma, d
   }
 
   // workspace: R[3] (r1, r2, y rotate), W[3] (w1, w2, w rotate) and the iterate block
-  const int64_t nb = n * BCOO_K;
+  const int64_t nb = n * K;
   if (c->mrb_ws_n < nb) {
     if (c->mrb_ws) HIPEIG_CHECK(hipFree(c->mrb_ws));
     c->mrb_ws = nullptr; c->mrb_ws_n = 0;
@@ -248,22 +257,22 @@ extern "C" int hipeig_minres_block(hipeig_ctx* c, hipeig_csr* A, double sigma, d
   double* R[3] = {c->mrb_ws, c->mrb_ws + c->mrb_ws_n, c->mrb_ws + 2 * c->mrb_ws_n};
   double* W[3] = {c->mrb_ws + 3 * c->mrb_ws_n, c->mrb_ws + 4 * c->mrb_ws_n, c->mrb_ws + 5 * c->mrb_ws_n};
   double* xw = c->mrb_ws + 6 * c->mrb_ws_n;
-  if (hipeig_block_pack(c, n, k, b, R[0])) return 1;
+  if (hipeig_block_pack(c, K, n, k, b, R[0])) return 1;
   HIPEIG_CHECK(hipMemsetAsync(R[1], 0, (size_t)c->mrb_ws_n * 6 * sizeof(double), c->stream));
   MinresState* V = c->d_mrb_state;
-  HIPEIG_CHECK(hipMemcpyAsync(V, h, BCOO_K * sizeof(MinresState), hipMemcpyHostToDevice, c->stream));
+  HIPEIG_CHECK(hipMemcpyAsync(V, h, K * sizeof(MinresState), hipMemcpyHostToDevice, c->stream));
   HIPEIG_CHECK(hipStreamSynchronize(c->stream));       // the pinned records are rewritten by the first copy-back
 
-  const int bv = hipeig_block_pick_variant(c, A);
+  const int bv = hipeig_block_pick_variant(c, A, K);
   if (bv < 0) return 1;
-  const BcooView tview = hipeig_bcoo_view(A);
+  const BcooView tview = hipeig_bcoo_view(A, K);
   if (bv == 2)
-    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_block_ka_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_block_ka_kernel<2, K>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)HIPEIG_BCOO_LDS_MAX));
-  const int gA = (bv == 2) ? (A->b_wgs_per_sweep < A->b_nunits ? A->b_wgs_per_sweep : A->b_nunits) : hipeig_rowowner_grid(c, A);
-  const int nsweepA = (bv == 2) ? (A->b_nunits + gA - 1) / gA : 1;
+  const int gA = (bv == 2) ? hipeig_bcoo_grid(A, K) : hipeig_rowowner_grid(c, A);
+  const int nsweepA = (bv == 2) ? (tview.nunits + gA - 1) / gA : 1;
   HIPEIG_REQUIRE((int64_t)nsweepA * gA <= HIPEIG_MAX_PARTIALS, "too many sweeps for the partial-sum buffer");
-  const int gE = grid_for(n * 4, 4);
+  const int gE = grid_for(n * (K / 2), 4);
   double* pA = c->d_partials;
   double* pC = c->d_partials + MRB_PART_STRIDE;
   double* pD = c->d_partials + 2 * MRB_PART_STRIDE;
@@ -286,31 +295,31 @@ extern "C" int hipeig_minres_block(hipeig_ctx* c, hipeig_csr* A, double sigma, d
     double* w1 = W[(it + 1) % 3];
     double* w2 = W[(it + 2) % 3];
     const double* xg = nullptr;
-    if (hipeig_block_allgather(c, A, r2, &xg)) return 4;
+    if (hipeig_block_allgather(c, A, K, r2, &xg)) return 4;
     if (bv == 2) {
       BcooView tv = tview;
       for (int sw = 0; sw < nsweepA; ++sw) {
         tv.unit_begin = sw * gA;
-        hipLaunchKernelGGL((minres_block_ka_kernel<2>), dim3(gA), dim3(BCOO_THREADS), hipeig_bcoo_lds_bytes(A), c->stream,
-                           tv, A->d_rowptr, A->d_col, A->d_val, n, xg, a, V + 0, V + 8, r2, r1, yb, pA + (size_t)sw * gA * BCOO_K);
+        hipLaunchKernelGGL((minres_block_ka_kernel<2, K>), dim3(gA), dim3(BCOO_THREADS), hipeig_bcoo_lds_bytes(A, K), c->stream,
+                           tv, A->d_rowptr, A->d_col, A->d_val, n, xg, a, V + 0, V + 8, r2, r1, yb, pA + (size_t)sw * gA * K);
       }
     } else {
-      hipLaunchKernelGGL((minres_block_ka_kernel<1>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream,
+      hipLaunchKernelGGL((minres_block_ka_kernel<1, K>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream,
                          tview, A->d_rowptr, A->d_col, A->d_val, n, xg, a, V + 0, V + 8, r2, r1, yb, pA);
     }
     if (dist) {
-      hipLaunchKernelGGL(sum_partials_cols8_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pA, nPA, red + 0);
-      if (hipeig_allreduce_sum(c, red + 0, 8)) return 4;
+      hipLaunchKernelGGL(sum_partials_cols_kernel<K>, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pA, nPA, red + 0);
+      if (hipeig_allreduce_sum(c, red + 0, K)) return 4;
     }
-    hipLaunchKernelGGL(minres_block_kc_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 8, V + 16, r2, yb, pC);
+    hipLaunchKernelGGL(minres_block_kc_kernel<K>, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 8, V + 16, r2, yb, pC);
     if (dist) {
-      hipLaunchKernelGGL(sum_partials_cols8_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pC, gE, red + 8);
-      if (hipeig_allreduce_sum(c, red + 8, 8)) return 4;
+      hipLaunchKernelGGL(sum_partials_cols_kernel<K>, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pC, gE, red + 8);
+      if (hipeig_allreduce_sum(c, red + 8, K)) return 4;
     }
-    hipLaunchKernelGGL(minres_block_kd_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 16, V + 0, r2, w1, w2, wn, xw, pD);
+    hipLaunchKernelGGL(minres_block_kd_kernel<K>, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 16, V + 0, r2, w1, w2, wn, xw, pD);
     if (dist) {
-      hipLaunchKernelGGL(sum_partials_cols8_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pD, gE, red + 16);
-      if (hipeig_allreduce_sum(c, red + 16, 8)) return 4;
+      hipLaunchKernelGGL(sum_partials_cols_kernel<K>, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pD, gE, red + 16);
+      if (hipeig_allreduce_sum(c, red + 16, K)) return 4;
     }
     return 0;
   };
@@ -325,14 +334,14 @@ extern "C" int hipeig_minres_block(hipeig_ctx* c, hipeig_csr* A, double sigma, d
       if (rc) return rc;
     }
     HIPEIG_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(minres_block_check_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, a, V + 0);
-    HIPEIG_CHECK(hipMemcpyAsync(h, V, BCOO_K * sizeof(MinresState), hipMemcpyDeviceToHost, c->stream));
+    hipLaunchKernelGGL(minres_block_check_kernel<K>, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, a, V + 0);
+    HIPEIG_CHECK(hipMemcpyAsync(h, V, K * sizeof(MinresState), hipMemcpyDeviceToHost, c->stream));
     HIPEIG_CHECK(hipStreamSynchronize(c->stream));
     all_done = true;
-    for (int j = 0; j < BCOO_K; ++j) all_done = all_done && h[j].done;
+    for (int j = 0; j < K; ++j) all_done = all_done && h[j].done;
   }
   HIPEIG_REQUIRE(all_done, "block MINRES left the iteration loop without a stop code in every column");
-  if (hipeig_block_unpack(c, n, k, xw, x)) return 1;
+  if (hipeig_block_unpack(c, K, n, k, xw, x)) return 1;
   for (int j = 0; j < k; ++j) {
     info[j] = (h[j].istop == 6) ? maxiter : 0;
     if (out_stats) {
@@ -342,4 +351,13 @@ extern "C" int hipeig_minres_block(hipeig_ctx* c, hipeig_csr* A, double sigma, d
     }
   }
   return 0;
+}
+
+extern "C" int hipeig_minres_block(hipeig_ctx* c, hipeig_csr* A, double sigma, double sign, int k,
+                                   const double* const* b, double* const* x, double rtol, int maxiter,
+                                   int* info, double* out_stats) {
+  HIPEIG_REQUIRE(k >= 1 && k <= BCOO_KMAX, "a block solve takes 1..8 right-hand sides");
+  // blocks of <= 4 use the narrow interleave: twice the accumulator rows per workgroup, half the vector traffic
+  if (k <= 4) return minres_block_impl<4>(c, A, sigma, sign, k, b, x, rtol, maxiter, info, out_stats);
+  return minres_block_impl<8>(c, A, sigma, sign, k, b, x, rtol, maxiter, info, out_stats);
 }

@@ -712,9 +712,11 @@ extern "C" int hipeig_csr_destroy(hipeig_ctx* c, hipeig_csr* A) {
   if (A->w_idx) hipFree(A->w_idx);
   if (A->w_val) hipFree(A->w_val);
   if (A->w_off) hipFree(A->w_off);
-  if (A->b_idx) hipFree(A->b_idx);
-  if (A->b_val) hipFree(A->b_val);
-  if (A->b_off) hipFree(A->b_off);
+  for (int q = 0; q < 2; ++q) {
+    if (A->bl[q].idx) hipFree(A->bl[q].idx);
+    if (A->bl[q].val) hipFree(A->bl[q].val);
+    if (A->bl[q].off) hipFree(A->bl[q].off);
+  }
   free(A);
   return 0;
 }

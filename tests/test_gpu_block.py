@@ -100,12 +100,13 @@ def _block_solve(hip, H, B, sigma, it, tol, reverse=False):
 
 
 @pytest.mark.parametrize("block_variant", [1, 2])
-@pytest.mark.parametrize("k,rtol", [(8, 1e-10), (3, 1e-6), (5, 1e-4), (11, 1e-8)])
+@pytest.mark.parametrize("k,rtol", [(8, 1e-10), (3, 1e-6), (4, 1e-8), (5, 1e-4), (11, 1e-8)])
 def test_block_minres_equals_the_single_solves(hip, gapped4000, block_variant, k, rtol):
     """Column j of the lock-step solve against hipeig_minres on b_j alone and against the oracle:
     iteration count and stop code equal, iterate within the solve tolerance.  Right-hand sides of very
     different difficulty (a near-eigenvector stops after a few iterations, a zero column at once), so
-    the masking of finished columns is exercised; k = 11 goes through two chunks of <= 8."""
+    the masking of finished columns is exercised; k <= 4 runs on the 4-wide interleave, 5..8 on the 8-wide one,
+    k = 11 goes through a chunk of 8 and a chunk of 3."""
     Hh, guess = gapped4000
     H = hip.HipCsrOperator.from_scipy(Hh)
     H.set_block_variant(block_variant)
@@ -154,9 +155,11 @@ def test_block_minres_nonconvergence_raises_and_fallbacks(hip, gapped4000):
     with pytest.raises(UserWarning):
         hip.HipVector.solveBlock(H, vecs, 0.02)
     assert all(v.last_solve_stats["iterations"] == 5 and v.last_solve_stats["istop"] == 6 for v in vecs)
-    one = hip.HipVector.solveBlock(H, [hip.HipVector(B[:, 0].copy(), _opts(2000, 1e-8))], 0.02)
-    ref = hip.HipVector.solve(H, hip.HipVector(B[:, 0].copy(), _opts(2000, 1e-8)), 0.02)
-    np.testing.assert_array_equal(one[0].array, ref.array)
+    for few in (1, 2):                       # below BLOCK_SOLVE_MIN right-hand sides: the one-by-one calls, bit for bit
+        got = hip.HipVector.solveBlock(H, [hip.HipVector(B[:, j].copy(), _opts(2000, 1e-8)) for j in range(few)], 0.02)
+        for j in range(few):
+            ref = hip.HipVector.solve(H, hip.HipVector(B[:, j].copy(), _opts(2000, 1e-8)), 0.02)
+            np.testing.assert_array_equal(got[j].array, ref.array)
     og = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 2000, "linear_tol": 1e-8, "linear_atol": 1e-10}}
     gs = hip.HipVector.solveBlock(H, [hip.HipVector(B[:, j].copy(), og) for j in range(2)], 0.02)
     for j in range(2):
