@@ -69,6 +69,7 @@ SIGNATURES = {
     "hipeig_csr_info": [_P, _I64P],
     "hipeig_csr_download": [_P, _P, _I64P, _I32P, _DP],
     "hipeig_csr_set_variant": [_P, C.c_int],
+    "hipeig_csr_set_reproducible": [_P, C.c_int],
     "hipeig_csr_fixed_info": [_P, _P, _DP],
     "hipeig_spmv": [_P, _P, _P, _P],
     "hipeig_spmv_shift": [_P, _P, _D, _D, _P, _P],

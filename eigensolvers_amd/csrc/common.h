@@ -113,6 +113,7 @@ struct hipeig_csr {
   uint32_t* w_off;
   int32_t w_nunits, w_nwin, w_wbits, w_rw, w_wgs_per_sweep;
   int32_t w_csplit;          // workgroups sharing one row block (column splits), 1 = none
+  int reproducible;          // automatic choice restricted to bitwise reproducible kernels (hipeig_csr_set_reproducible)
   double absrow_max;         // max_i sum_j |a_ij| over the local rows: overflow bound of the fixed-point sweep (variant 5)
   // block-operand copies ("TCOO-B", spmm_device.h): one per interleave width, [0]: K = 4, [1]: K = 8; built on first use
   struct BcooLayout {

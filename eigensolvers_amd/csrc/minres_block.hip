@@ -41,6 +41,7 @@ struct MinresBlockEpilogue {
   const double* __restrict__ r2l;    // local rows of R2 (v = s*r2)
   const double* __restrict__ r1;
   double* __restrict__ y;
+  double* yy;                        // fused (row-partitioned) form: running <y_j, y_j> of this thread, else null
   __device__ __forceinline__ void elem(int64_t r, int j, double sum, double& acc) const {
     const int64_t i = r * K + j;
     const double v = s * r2l[i];
@@ -48,11 +49,15 @@ struct MinresBlockEpilogue {
     if (use_r1) yv -= c1 * r1[i];
     y[i] = yv;
     acc = fma(v, yv, acc);
+    if (yy) *yy = fma(yv, yv, *yy);
   }
 };
 
 // VARIANT 2: window-blocked (TCOO-B) sweep, 1024 threads; VARIANT 1: row-owner CSR sweep, 256 threads.
-template <int VARIANT, int K>
+// FUSED = 1: the form of a row-partitioned run, as in minres.hip - the sweep also leaves the partials of
+// <y_j, y_j> (one area further, at partials + MRB_PART_STRIDE) so that beta^2 = <y,y> - alfa^2 needs no second
+// reduction, and the stopping tests move to the fused update kernel, where the lagged <x,x> arrives.
+template <int VARIANT, int K, int FUSED = 0>
 __global__ void __launch_bounds__(VARIANT == 2 ? BCOO_THREADS : HIPEIG_BLOCK)
 minres_block_ka_kernel(BcooView T, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                        const double* __restrict__ val, int64_t nrows, const double* __restrict__ xg, MinresArgs a,
@@ -63,12 +68,12 @@ minres_block_ka_kernel(BcooView T, const int32_t* __restrict__ rowptr, const int
   __shared__ double sh_s[K], sh_c1[K];
   __shared__ int sh_use[K], sh_live;
   extern __shared__ double bcoo_lds[];
-  const double xx = sum_or_value_cols<K>(a.pD, a.nD, red);
+  const double xx = FUSED ? 0.0 : sum_or_value_cols<K>(a.pD, a.nD, red);
   if (threadIdx.x == 0) sh_live = 0;
   __syncthreads();
   if (threadIdx.x < K) {
     MinresState S = Sin[threadIdx.x];
-    minres_tests(S, (S.itn > 0 && !S.done) ? xx : 0.0, a);
+    if (!FUSED) minres_tests(S, (S.itn > 0 && !S.done) ? xx : 0.0, a);
     if (blockIdx.x == 0) Sout[threadIdx.x] = S;
     const int use = (!S.done && S.itn >= 1);
     sh_s[threadIdx.x] = S.done ? 0.0 : S.s;
@@ -82,11 +87,16 @@ minres_block_ka_kernel(BcooView T, const int32_t* __restrict__ rowptr, const int
   const int j = threadIdx.x % K;
   epi.sigma = a.sigma; epi.sign = a.sign; epi.s = sh_s[j]; epi.c1 = sh_c1[j]; epi.use_r1 = sh_use[j];
   epi.r2l = r2l; epi.r1 = r1; epi.y = y;
-  double acc = 0.0;
+  double acc = 0.0, acc_yy = 0.0;
+  epi.yy = FUSED ? &acc_yy : nullptr;
   if (VARIANT == 2) bcoo_wg_sweep<K>(T, xg, epi, acc, bcoo_lds);
   else csr_rowowner_block_sweep<K>(rowptr, col, val, nrows, xg, epi, acc);
   const double tot = block_reduce_cols<K>(acc, red);
   if (threadIdx.x < K) partials[(size_t)blockIdx.x * K + threadIdx.x] = tot;
+  if (FUSED) {
+    const double tyy = block_reduce_cols<K>(acc_yy, red);
+    if (threadIdx.x < K) partials[MRB_PART_STRIDE + (size_t)blockIdx.x * K + threadIdx.x] = tyy;
+  }
 }
 
 // Fold (a0, a1) - partials of operands 2(t % (K/2)) and the next - over the workgroup; record in threads 0..K-1.
@@ -186,6 +196,75 @@ minres_block_kd_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ 
   block_reduce_pairs<K>(a0, a1, red, partials + (size_t)blockIdx.x * K);
 }
 
+// Fused second half of an iteration of a row-partitioned run (the block form of minres_kcd_fused_kernel):
+// per column the stopping tests of the PREVIOUS iteration (its <x,x> has just arrived with the all-reduce),
+// then KC and KD in one pass.  a.pA / a.pC / a.pD point at the three all-reduced records of K sums.
+template <int K>
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+minres_block_kcd_fused_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, MinresState* __restrict__ Sout,
+                              const double* __restrict__ r2, double* __restrict__ y, const double* __restrict__ w1,
+                              const double* __restrict__ w2, double* __restrict__ w, double* __restrict__ x,
+                              double* __restrict__ partials) {
+  __shared__ double red[HIPEIG_BLOCK / 64 * K];
+  __shared__ double sh_c[K], sh_sold[K], sh_oldeps[K], sh_delta[K], sh_denom[K], sh_phi[K];
+  __shared__ int sh_done[K];
+  if (threadIdx.x < K) {
+    MinresState S = Sin[threadIdx.x];
+    if (!S.done) minres_tests(S, S.itn > 0 ? a.pD[threadIdx.x] : 0.0, a);
+    sh_sold[threadIdx.x] = S.s;
+    double c = 0.0;
+    if (!S.done) {
+      S.alfa = a.pA[threadIdx.x];
+      c = S.alfa / S.beta;
+      minres_advance(S, fmax(a.pC[threadIdx.x] - S.alfa * S.alfa, 0.0));
+    }
+    if (blockIdx.x == 0) Sout[threadIdx.x] = S;
+    sh_c[threadIdx.x] = c;
+    sh_oldeps[threadIdx.x] = S.oldeps; sh_delta[threadIdx.x] = S.delta;
+    sh_denom[threadIdx.x] = S.denom; sh_phi[threadIdx.x] = S.phi;
+    sh_done[threadIdx.x] = S.done;
+  }
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int j0 = (int)(t0 % (K / 2)) * 2, j1 = j0 + 1;
+  const double c0 = sh_c[j0], s0 = sh_sold[j0], e0 = sh_oldeps[j0], d0 = sh_delta[j0], q0 = sh_denom[j0], p0 = sh_phi[j0];
+  const double c1 = sh_c[j1], s1 = sh_sold[j1], e1 = sh_oldeps[j1], d1 = sh_delta[j1], q1 = sh_denom[j1], p1 = sh_phi[j1];
+  const bool live0 = !sh_done[j0], live1 = !sh_done[j1];
+  const double2* r22 = reinterpret_cast<const double2*>(r2);
+  const double2* w12 = reinterpret_cast<const double2*>(w1);
+  const double2* w22 = reinterpret_cast<const double2*>(w2);
+  double2* y2 = reinterpret_cast<double2*>(y);
+  double2* wn2 = reinterpret_cast<double2*>(w);
+  double2* x2 = reinterpret_cast<double2*>(x);
+  double a0 = 0.0, a1 = 0.0;
+  for (int64_t t = t0; t < n * (K / 2); t += stride) {
+    const double2 rv = r22[t], b1 = w12[t], b2 = w22[t];
+    double2 yv = y2[t], xv = x2[t], wn;
+    yv.x -= c0 * rv.x; yv.y -= c1 * rv.y;
+    wn.x = (s0 * rv.x - e0 * b1.x - d0 * b2.x) * q0;
+    wn.y = (s1 * rv.y - e1 * b1.y - d1 * b2.y) * q1;
+    if (live0) xv.x += p0 * wn.x;                        // a stopped column keeps its iterate
+    if (live1) xv.y += p1 * wn.y;
+    y2[t] = yv; wn2[t] = wn; x2[t] = xv;
+    a0 = fma(xv.x, xv.x, a0); a1 = fma(xv.y, xv.y, a1);
+  }
+  block_reduce_pairs<K>(a0, a1, red, partials + (size_t)blockIdx.x * K);
+}
+
+// Row-partitioned run: this rank's three records (<v,y>, <y,y>, lagged <x,x>) of K sums each, at out + 0 / 8 / 16,
+// from the three partial areas - ONE all-reduce of 24 doubles follows.  One workgroup per record.
+template <int K>
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+sum_three_records_kernel(const double* __restrict__ pA, int nA, const double* __restrict__ pC, int nC,
+                         const double* __restrict__ pD, int nD, double* __restrict__ out) {
+  __shared__ double red[HIPEIG_BLOCK / 64 * K];
+  const double* p = blockIdx.x == 0 ? pA : blockIdx.x == 1 ? pC : pD;
+  const int cnt = blockIdx.x == 0 ? nA : blockIdx.x == 1 ? nC : nD;
+  const double v = block_sum_partials_cols<K>(p, cnt, red);
+  if (threadIdx.x < K) out[blockIdx.x * 8 + threadIdx.x] = v;
+}
+
 // End-of-chunk evaluation of the stopping tests (what KA's prologue would do next).
 template <int K>
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
@@ -278,14 +357,18 @@ static int minres_block_impl(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   double* pD = c->d_partials + 2 * MRB_PART_STRIDE;
   HIPEIG_REQUIRE(c->partials_doubles >= (size_t)3 * MRB_PART_STRIDE, "partial-sum workspace too small");
   const bool dist = c->collectives != 0;
-  double* red = c->d_scalars + 2048;                  // three reduced records of 8 for the distributed path
+  double* red = c->d_scalars + 2048;                  // row-partitioned run: three reduced records of 8 (+ one for the chunk check)
   MinresArgs a;
   a.sigma = sigma; a.sign = sign; a.rtol = rtol; a.maxiter = maxiter;
   const int nPA = gA * nsweepA;
   a.pA = dist ? red + 0 : pA; a.nA = dist ? 1 : nPA;
   a.pC = dist ? red + 8 : pC; a.nC = dist ? 1 : gE;
   a.pD = dist ? red + 16 : pD; a.nD = dist ? 1 : gE;
-  if (dist) HIPEIG_CHECK(hipMemsetAsync(red, 0, 24 * sizeof(double), c->stream));
+  if (dist) {
+    HIPEIG_CHECK(hipMemsetAsync(red, 0, 32 * sizeof(double), c->stream));
+    HIPEIG_CHECK(hipMemsetAsync(pD, 0, (size_t)gE * K * sizeof(double), c->stream));     // the lagged <x,x> of "iteration -1"
+  }
+  c->mr_collectives = 0;
 
   auto enqueue_iteration = [&](int it) -> int {
     double* r2 = R[it % 3];
@@ -296,6 +379,26 @@ static int minres_block_impl(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
     double* w2 = W[(it + 2) % 3];
     const double* xg = nullptr;
     if (hipeig_block_allgather(c, A, K, r2, &xg)) return 4;
+    if (dist) {
+      // all-gather + sweep, ONE all-reduce of the three records, fused update: 2 collectives per iteration
+      ++c->mr_collectives;
+      if (bv == 2) {
+        BcooView tv = tview;
+        for (int sw = 0; sw < nsweepA; ++sw) {
+          tv.unit_begin = sw * gA;
+          hipLaunchKernelGGL((minres_block_ka_kernel<2, K, 1>), dim3(gA), dim3(BCOO_THREADS), hipeig_bcoo_lds_bytes(A, K), c->stream,
+                             tv, A->d_rowptr, A->d_col, A->d_val, n, xg, a, V + 0, V + 8, r2, r1, yb, pA + (size_t)sw * gA * K);
+        }
+      } else {
+        hipLaunchKernelGGL((minres_block_ka_kernel<1, K, 1>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream,
+                           tview, A->d_rowptr, A->d_col, A->d_val, n, xg, a, V + 0, V + 8, r2, r1, yb, pA);
+      }
+      hipLaunchKernelGGL(sum_three_records_kernel<K>, dim3(3), dim3(HIPEIG_BLOCK), 0, c->stream, pA, nPA, pC, nPA, pD, gE, red);
+      if (hipeig_allreduce_sum(c, red, 24)) return 4;
+      ++c->mr_collectives;
+      hipLaunchKernelGGL(minres_block_kcd_fused_kernel<K>, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 8, V + 0, r2, yb, w1, w2, wn, xw, pD);
+      return 0;
+    }
     if (bv == 2) {
       BcooView tv = tview;
       for (int sw = 0; sw < nsweepA; ++sw) {
@@ -307,20 +410,8 @@ static int minres_block_impl(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
       hipLaunchKernelGGL((minres_block_ka_kernel<1, K>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream,
                          tview, A->d_rowptr, A->d_col, A->d_val, n, xg, a, V + 0, V + 8, r2, r1, yb, pA);
     }
-    if (dist) {
-      hipLaunchKernelGGL(sum_partials_cols_kernel<K>, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pA, nPA, red + 0);
-      if (hipeig_allreduce_sum(c, red + 0, K)) return 4;
-    }
     hipLaunchKernelGGL(minres_block_kc_kernel<K>, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 8, V + 16, r2, yb, pC);
-    if (dist) {
-      hipLaunchKernelGGL(sum_partials_cols_kernel<K>, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pC, gE, red + 8);
-      if (hipeig_allreduce_sum(c, red + 8, K)) return 4;
-    }
     hipLaunchKernelGGL(minres_block_kd_kernel<K>, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 16, V + 0, r2, w1, w2, wn, xw, pD);
-    if (dist) {
-      hipLaunchKernelGGL(sum_partials_cols_kernel<K>, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pD, gE, red + 16);
-      if (hipeig_allreduce_sum(c, red + 16, K)) return 4;
-    }
     return 0;
   };
 
@@ -334,7 +425,16 @@ static int minres_block_impl(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
       if (rc) return rc;
     }
     HIPEIG_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(minres_block_check_kernel<K>, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, a, V + 0);
+    MinresArgs ac = a;
+    if (dist) {
+      // the last iteration's <x,x> has not been through an all-reduce yet: reduce a separate record for the
+      // check; the partial area itself joins the next iteration's record
+      hipLaunchKernelGGL(sum_partials_cols_kernel<K>, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pD, gE, red + 24);
+      if (hipeig_allreduce_sum(c, red + 24, K)) return 4;
+      ++c->mr_collectives;
+      ac.pD = red + 24;
+    }
+    hipLaunchKernelGGL(minres_block_check_kernel<K>, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, ac, V + 0);
     HIPEIG_CHECK(hipMemcpyAsync(h, V, K * sizeof(MinresState), hipMemcpyDeviceToHost, c->stream));
     HIPEIG_CHECK(hipStreamSynchronize(c->stream));
     all_done = true;

@@ -139,7 +139,7 @@ int hipeig_block_pick_variant(hipeig_ctx* c, hipeig_csr* A, int K) {
   if (A->block_variant == 1 || A->nnz == 0 || A->nrows == 0) return A->last_block_variant = 1;
   // an operator pinned to a reproducible kernel (variants 1-3, 5) keeps that promise for block products and block
   // solves too: the row-owner kernel adds a row's terms in a fixed order, the window-blocked one uses fp64 atomics
-  if (A->block_variant == 0 && A->variant != 0 && A->variant != 4) return A->last_block_variant = 1;
+  if (A->block_variant == 0 && (A->reproducible || (A->variant != 0 && A->variant != 4))) return A->last_block_variant = 1;
   if (L.state == 1) return A->last_block_variant = 2;
   if (L.state == 2 && A->block_variant == 0) return A->last_block_variant = 1;
   int wbits = K == 8 ? 11 : 12;                          // 128 KiB of the operand block per window (measured best of 2^8..2^15 rows at N = 1e6,

@@ -568,7 +568,7 @@ int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A) {
   int variant = A->variant;
   if (variant == 0) {
     // the gathered operand does not fit one XCD's L2 -> window it; small problems stream
-    variant = (A->gather_len * 8 > (int64_t)3 << 20 && A->nnz > (int64_t)1 << 20) ? 4 : 2;
+    variant = (A->gather_len * 8 > (int64_t)3 << 20 && A->nnz > (int64_t)1 << 20) ? (A->reproducible ? 5 : 4) : 2;
   }
   if (variant == 4 || variant == 5) {
     const int rc = hipeig_csr_build_tcoow(c, A);
@@ -743,6 +743,11 @@ extern "C" int hipeig_csr_fixed_info(hipeig_ctx* c, hipeig_csr* A, double out[2]
 extern "C" int hipeig_csr_set_variant(hipeig_csr* A, int variant) {
   HIPEIG_REQUIRE(variant >= 0 && variant <= 5, "unknown variant");
   A->variant = variant;
+  return 0;
+}
+
+extern "C" int hipeig_csr_set_reproducible(hipeig_csr* A, int on) {
+  A->reproducible = on ? 1 : 0;
   return 0;
 }
 

@@ -209,17 +209,24 @@ class HipCsrOperator:
         self._variant = int(variant)
 
     def honour_reduction_option(self, options):
-        """``options["reduction"]`` of the vectors: "deterministic" makes an operator that is
-        on the automatic / fast kernel use the fixed-point one (variant 5, bitwise reproducible at the same speed),
-        "fast" puts it back on the automatic choice.  An explicitly pinned variant 1-3 is left alone."""
+        """``options["reduction"]`` of the vectors: "deterministic" restricts the operator to
+        bitwise reproducible kernels - on the automatic choice CSR-stream stays, the fixed-point variant 5 takes the
+        place of the fp64-atomic variant 4 (same speed) and block products take the row-owner kernel; an operator
+        pinned to 4 moves to 5.  "fast" undoes both.  An explicitly pinned variant 1-3 is left alone."""
         want = (options or {}).get("reduction")
-        cur = getattr(self, "_variant", 0)
-        if want == "deterministic" and cur in (0, 4):
-            self.set_variant(5)
-        elif want == "fast" and cur == 5:
-            self.set_variant(0)
-        elif want not in (None, "deterministic", "fast"):
+        if want not in (None, "deterministic", "fast"):
             raise ValueError(f'options["reduction"] must be "deterministic" or "fast", got {want!r}')
+        if want is None or want == getattr(self, "_reduction", None):
+            return
+        cur = getattr(self, "_variant", 0)
+        _lib.call("hipeig_csr_set_reproducible", self.handle, 1 if want == "deterministic" else 0)
+        if want == "deterministic" and cur == 4:
+            self.set_variant(5)
+            self._moved_by_option = True
+        elif want == "fast" and cur == 5 and getattr(self, "_moved_by_option", False):
+            self.set_variant(4)
+            self._moved_by_option = False
+        self._reduction = want
 
     def fixed_point_info(self):
         """(max_i sum_j |a_ij|, max |x| of the last variant-5 operand): what bounds variant 5's absolute error."""
@@ -551,12 +558,19 @@ class HipVector(AbstractVector):
             stats = (C.c_double * (8 * k))()
             _lib.call("hipeig_minres_block", ctx.handle, H.handle, float(sigma), -1.0 if reverseGF else 1.0, k,
                       bt, xt, float(o["linear_tol"]), int(o["linearIter"]), info, stats)
+            ncoll = None
+            if ctx.nranks > 1 or os.environ.get("HIPEIG_FORCE_COLLECTIVES", "0") not in ("", "0"):
+                cs = (C.c_int64 * 4)()
+                _lib.call("hipeig_comm_stats", ctx.handle, cs)
+                ncoll = int(cs[0])                 # collectives of the whole lock-step solve (all columns together)
             for j, b in enumerate(chunk):
                 res = b._new(outs[j])
                 st = stats[8 * j:8 * j + 8]
                 res.last_solve_stats = b.last_solve_stats = {
                     "iterations": int(st[0]), "istop": int(st[1]), "rnorm": st[2], "Anorm": st[3],
                     "ynorm": st[4], "test1": st[5], "test2": st[6], "Acond": st[7]}
+                if ncoll is not None:
+                    res.last_solve_stats["collectives"] = ncoll
                 results.append(res)
             if any(info[j] != 0 for j in range(k)):
                 raise UserWarning("Warning:: Iterative solver is not converged ")

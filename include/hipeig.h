@@ -164,6 +164,10 @@ int hipeig_csr_download(hipeig_ctx* ctx, hipeig_csr* A, int64_t* rowptr, int32_t
  * accumulators: bitwise reproducible whatever the order in which waves reach a row, same speed; absolute error per
  * row ~ nnz_row * 2^-61 * max_i sum_j|a_ij| * max|x|) */
 int hipeig_csr_set_variant(hipeig_csr* A, int variant);
+/* options["reduction"] = "deterministic" of the vectors: on != 0 restricts the AUTOMATIC choice
+ * (variant 0) to bitwise reproducible kernels - CSR-stream where it would be picked anyway, variant 5 in place of 4,
+ * the row-owner kernel for block products.  A pinned variant is not touched.                                      */
+int hipeig_csr_set_reproducible(hipeig_csr* A, int on);
 /* variant 5's error-bound ingredients: out[0] = max_i sum_j |a_ij| over the local rows, out[1] = max |x| of the
  * operand of the most recent variant-5 product; absolute error per row <= (nnz_row/2 + 1) * 2^-60 * out[0] * out[1] */
 int hipeig_csr_fixed_info(hipeig_ctx* ctx, hipeig_csr* A, double out[2]);

@@ -150,9 +150,10 @@ def test_checkpoint_resume_is_bit_for_bit_with_the_fixed_point_kernel(hip, tmp_p
 
 
 def test_reduction_option_selects_the_reproducible_kernel(hip):
-    """``options["reduction"] = "deterministic" | "fast"`` on the vectors."""
+    """``options["reduction"] = "deterministic" | "fast"`` on the vectors restricts / frees the
+    operator's automatic kernel choice."""
     from eigensolvers_amd.generators import guess_vector
-    N = 300_000
+    N = 500_000                                   # 4 MB operand: the automatic choice is the window-blocked sweep
     H = hip.HipCsrOperator.generate(N, 32, seed=5)
     g = guess_vector(N, 2)
     runs = []
@@ -163,6 +164,27 @@ def test_reduction_option_selects_the_reproducible_kernel(hip):
         runs.append((ev, Y[0].array))
     np.testing.assert_array_equal(runs[0][0], runs[1][0])
     np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    # block products of a "deterministic" operator take the row-owner kernel (fixed order inside a row)
+    xs = [hip.HipVector(guess_vector(N, 3 + j).copy(), o) for j in range(4)]
+    W1 = [w.array for w in hip.HipVector.solveBlock(H, xs, 0.02)]
+    assert H.block_info()["variant"] == "row-owner"
+    W2 = [w.array for w in hip.HipVector.solveBlock(H, xs, 0.02)]
+    for a, b in zip(W1, W2):
+        np.testing.assert_array_equal(a, b)
+    o = _opts(); o["reduction"] = "fast"
+    hip.HipVector(g.copy(), o).applyOp(H)
+    assert H.last_variant() == "column-window-blocked(workgroup)"
+    hip.HipVector.solveBlock(H, [hip.HipVector(x.array, o) for x in xs], 0.02)
+    assert H.block_info()["variant"] == "column-window-blocked"
+    # where the automatic choice is reproducible anyway (CSR-stream below an L2's worth of operand) it stays
+    Hs = hip.HipCsrOperator.generate(100_000, 32, seed=5)
+    o = _opts(); o["reduction"] = "deterministic"
+    hip.HipVector(guess_vector(100_000, 2).copy(), o).applyOp(Hs)
+    assert Hs.last_variant() == "csr-stream"
+    # a pinned fast kernel moves to its reproducible twin and back
+    H.set_variant(4)
+    hip.HipVector(g.copy(), o).applyOp(H)
+    assert H.last_variant() == "column-window-blocked(workgroup, fixed-point)"
     o = _opts(); o["reduction"] = "fast"
     hip.HipVector(g.copy(), o).applyOp(H)
     assert H.last_variant() == "column-window-blocked(workgroup)"

@@ -162,13 +162,32 @@ def test_config5_feast_converges_at_2e4(hip):
     same recipe is profiles/r02_config5_feast_n1e6.json).  All 16 window eigenvalues found, each a certified
     eigenpair, the one next to sigma = 0.02 equal to a Lanczos run's on the same operator.  (Convergence is slow
     by construction: with positiveHalf the reference integrates over a quarter circle, util_funcs.py:161-164.)"""
-    N, m0 = 20_000, 16
-    H = hip.HipCsrOperator.generate(N, 32, seed=7)
+    from eigensolvers_amd.distributed import ContourReplicas, LoopbackGroup
+    N, m0, P = 20_000, 16, 4
     Q = la.qr(np.random.default_rng(9).standard_normal((N, m0)), mode="economic")[0]
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        ev, Y, st = hip.feastDiagonalization(H, [hip.HipVector(Q[:, i].copy(), _opts("gcrotmk", 4000, 1e-5)) for i in range(m0)],
-                                             16, "legendre", -0.21, 0.21, 1e-4, 12, writeOut=False)
+
+    def run(rank, ctx):
+        # contour point k on replica k mod 4 (SURVEY 8e's FEAST mapping, here as 4 host threads on the one GPU:
+        # the launch-bound GCROT solves of different contour points overlap - 52 s instead of 107 s serially)
+        comm = ContourReplicas(ctx)                     # replica mode first: operator and vectors are whole on every rank
+        Hr = hip.HipCsrOperator.generate(N, 32, seed=7, ctx=ctx)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ev, Y, st = hip.feastDiagonalization(Hr, [hip.HipVector(Q[:, i].copy(), _opts("gcrotmk", 4000, 1e-5), ctx=ctx) for i in range(m0)],
+                                                 16, "legendre", -0.21, 0.21, 1e-4, 12, writeOut=False, contourComm=comm)
+        return ev, [y.array for y in Y], st
+
+    grp = LoopbackGroup(P)
+    try:
+        res_all = grp.run(run)
+    finally:
+        grp.close()
+    for ev_r, _, st_r in res_all:
+        np.testing.assert_array_equal(ev_r, res_all[0][0])          # every replica ends with the same data
+        assert st_r["outerIter"] == res_all[0][2]["outerIter"]
+    ev, Yh, st = res_all[0]
+    H = hip.HipCsrOperator.generate(N, 32, seed=7)
+    Y = [hip.HipVector(y, _opts()) for y in Yh]
     assert st["residual"] < 1e-4 and len(Y) == m0 and 2 <= st["outerIter"] < 11
     inside = np.sort(ev[(ev > -0.21) & (ev < 0.21)])
     assert len(inside) == 16

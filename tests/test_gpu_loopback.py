@@ -221,6 +221,7 @@ def test_block_product_and_block_solve_on_two_ranks(hip, monkeypatch):
             W = hip.HipVector.solveBlock(H, [hip.HipVector(Bh[b:e, j].copy(), dict(opts), ctx=ctx) for j in range(k)], 0.02)
             out[f"w{bv}"] = [w.array for w in W]
             out[f"it{bv}"] = [w.last_solve_stats["iterations"] for w in W]
+            out[f"coll{bv}"] = W[0].last_solve_stats["collectives"]
             out[f"kind{bv}"] = H.block_info()["variant"]
         return out, (b, e)
 
@@ -231,6 +232,10 @@ def test_block_product_and_block_solve_on_two_ranks(hip, monkeypatch):
     for bv, kind in ((1, "row-owner"), (2, "column-window-blocked")):
         assert all(o[f"kind{bv}"] == kind for o, _ in res)
         assert res[0][0][f"it{bv}"] == res[1][0][f"it{bv}"]
+        # fused reductions of the block solve: per iteration one all-gather of the interleaved operand block and
+        # ONE all-reduce of the three records (<v,y>, <y,y>, lagged <x,x>) for all columns, + one per 16-iteration chunk
+        done = 16 * -(-(max(res[0][0][f"it{bv}"]) + 1) // 16)        # the loop runs whole chunks (the stop is seen at the check)
+        assert 2 * max(res[0][0][f"it{bv}"]) <= res[0][0][f"coll{bv}"] <= 2 * done + done // 16 + 2, (res[0][0][f"coll{bv}"], done)
         for j in range(k):
             y = np.concatenate([o[f"y{bv}"][j] for o, _ in res])
             assert np.max(np.abs(y - ref[j])) <= 1e-13 * np.max(np.abs(ref[j]))
