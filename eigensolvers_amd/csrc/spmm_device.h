@@ -166,11 +166,31 @@ __device__ __forceinline__ void csr_rowowner_block_sweep(const int32_t* __restri
   const int r = lane % K, sl = lane / K;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  constexpr int NPI = 64 / K;                 // non-zeros per wave instruction
+#ifndef ROWOWNER_UNROLL
+#define ROWOWNER_UNROLL 2                     // gather instructions in flight per wave (a lane adds its terms in ascending order
+#endif                                        // whatever the unroll: same bits)
   for (int64_t row = wave; row < nrows; row += nwaves) {
     const int s = rowptr[row], e = rowptr[row + 1];
     double a = 0.0;
-    for (int p = s + sl; p < e; p += 64 / K)
-      a = fma(__builtin_nontemporal_load(val + p), X[(int64_t)__builtin_nontemporal_load(col + p) * K + r], a);
+    for (int p0 = s + sl; p0 - sl < e; p0 += ROWOWNER_UNROLL * NPI) {
+      double v[ROWOWNER_UNROLL], xv[ROWOWNER_UNROLL];
+      int cc[ROWOWNER_UNROLL];
+      // unconditional loads from clamped positions (e - 1 is a term of this row), masked afterwards: the compiler
+      // then keeps all the gathers of a batch in flight instead of draining them one by one (exec-masked loads)
+#pragma unroll
+      for (int u = 0; u < ROWOWNER_UNROLL; ++u) {
+        const int p = p0 + u * NPI;
+        const int pc = p < e ? p : e - 1;
+        cc[u] = __builtin_nontemporal_load(col + pc);
+        v[u] = __builtin_nontemporal_load(val + pc);
+      }
+#pragma unroll
+      for (int u = 0; u < ROWOWNER_UNROLL; ++u) xv[u] = X[(int64_t)cc[u] * K + r];
+#pragma unroll
+      for (int u = 0; u < ROWOWNER_UNROLL; ++u)
+        if (p0 + u * NPI < e) a = fma(v[u], xv[u], a);
+    }
 #pragma unroll
     for (int off = 32; off >= K; off >>= 1) a += __shfl_down(a, off, 64);
     if (sl == 0) epi.elem(row, r, a, acc);
