@@ -67,6 +67,9 @@ def _candidate_ports():
     return [20000 + (mp * 7 + 13 + 101 * k) % 20000 for k in range(8)]
 
 
+_exchange_seq = 0
+
+
 def _run_token():
     return (os.environ.get("TORCHELASTIC_RUN_ID", "none") + ":" + os.environ.get("MASTER_PORT", "29511")).encode()
 
@@ -79,7 +82,11 @@ def exchange_bytes(payload, nbytes, rank, world, timeout=300.0):
     if world == 1:
         return bytes(payload)
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-    token = _MAGIC + b"|" + _run_token()
+    # the n-th exchange of this job only talks to the n-th exchange of the other ranks: a rank that is already one
+    # exchange ahead is turned away (and retries) instead of being handed the previous record
+    global _exchange_seq
+    _exchange_seq += 1
+    token = _MAGIC + b"|" + _run_token() + b"#" + str(_exchange_seq).encode()
     if rank == 0:
         srv = None
         for port in _candidate_ports():

@@ -124,3 +124,19 @@ def test_feast_contour_replicas_match_the_serial_run(tmp_path, world):
         np.testing.assert_array_equal(r[k]["y0"], r[0]["y0"])
         np.testing.assert_allclose(r[k]["ev"], g["ev"], rtol=1e-9)
         assert int(r[k]["outerIter"]) == int(g["outerIter"]) and int(r[k]["nvec"]) == int(g["nvec"])
+
+
+@pytest.mark.timeout(300)
+def test_rendezvous_under_the_real_launcher(tmp_path):
+    """bench.py --gpus N is started by ``python -m torch.distributed.run``; the product reads the launcher's
+    environment and exchanges RCCL's 128-byte id over its own TCP channel without importing torch
+    (tools/rendezvous_check.py asserts that in every rank).  Three ranks, the driver's command line."""
+    import subprocess
+    world = 3
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(REPO, "tools", "rendezvous_check.py"), str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for k in range(world):
+        assert (tmp_path / f"rank{k}of{world}.txt").read_text().split() == [str(k), str(world), str(k), "1"]
