@@ -1,13 +1,20 @@
-"""BASELINE config #5 shape at N = 1e6 run to the reference's stopping rule; writes a JSON summary."""
+"""BASELINE config #5 shape run to the reference's stopping rule (or for argv[2] FEAST iterations); JSON summary on stdout.
+python tools/experiments/feast_profile_run.py [N [maxit]]"""
 import json, os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.linalg as la
 import eigensolvers_amd as ea
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-tol, econv, maxit, m0 = 1e-5, 1e-4, 12, 16
+tol, econv, maxit, m0 = 1e-5, 1e-4, (int(sys.argv[2]) if len(sys.argv) > 2 else 12), 16
 H = ea.HipCsrOperator.generate(N, 32 if N <= 2_000_000 else 64, seed=7)
 Q = la.qr(np.random.default_rng(9).standard_normal((N, m0)), mode="economic")[0]
 opt = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 4000, "linear_tol": tol, "linear_atol": tol * 1e-2}}
+import threading
+def _heartbeat(t0=time.time()):                 # a line a minute: a silent long run is taken for a hung one on the GPU box
+    while True:
+        time.sleep(60)
+        print("... %.0f s" % (time.time() - t0), file=sys.stderr, flush=True)
+threading.Thread(target=_heartbeat, daemon=True).start()
 t = time.time()
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
