@@ -50,7 +50,7 @@ int hipeig_comm_library(char* path, int path_len);
 int hipeig_comm_init(hipeig_ctx* ctx, int nranks, int rank, const void* id128);
 int hipeig_comm_destroy(hipeig_ctx* ctx);
 int hipeig_comm_info(hipeig_ctx* ctx, int* nranks, int* rank);
-/* stats[0] = collectives (operand all-gathers + all-reduces) issued by the most recent hipeig_minres call of
+/* stats[0] = collectives (operand all-gathers + all-reduces) issued by the most recent hipeig_minres / hipeig_minres_block call of
  * this rank: a row-partitioned MINRES iteration costs two - the all-gather of the operand and ONE fused
  * all-reduce carrying <v,y>, <y,y> and the previous iteration's <x,x>.           */
 int hipeig_comm_stats(hipeig_ctx* ctx, int64_t stats[4]);
