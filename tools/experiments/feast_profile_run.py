@@ -22,6 +22,6 @@ with warnings.catch_warnings():
 dt = time.time() - t
 res = ea.true_residual_norms(H, ev, Y, len(Y))
 print(json.dumps({"config": "FEAST, window [-0.21, 0.21], nc = 16 (8 half-contour points), m0 = 16, gcrotmk rtol 1e-5, eConv 1e-4",
-                  "N": N, "nnz": int(H.nnz), "outerIter": int(st["outerIter"]), "residual": float(st["residual"]), "converged": bool(st["residual"] < econv),
+                  "N": N, "nnz": int(H.nnz), "outerIter": int(st["outerIter"]), "residual": (None if st["residual"] is None else float(st["residual"])), "converged": bool(st["residual"] is not None and st["residual"] < econv),
                   "seconds": round(dt, 1), "seconds_per_feast_iteration": round(dt / (st["outerIter"] + 1), 1),
                   "eigenvalues_in_window": np.sort(ev[(ev > -0.21) & (ev < 0.21)]).tolist(), "true_residual_norms": res.tolist()}, indent=1))
