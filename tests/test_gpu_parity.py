@@ -601,3 +601,35 @@ def test_reference_unit_tests_with_gcrotmk_on_device(hip):
     w, V = np.linalg.eigh(Ab)
     lan = np.vstack([Y[i].array for i in range(3)]).T
     assert abs(np.abs(la.eigvals(lan.T @ V[:, 5:8])).sum() - 3) < 1e-6       # projector trace, :56-62
+
+
+def test_reference_lindep_test_case_on_device(hip):
+    """unittests/test_lanczosLINDEP.py with HipVector (dense n = 1200 operator, gcrotmk rtol 1e-1, sigma = 390, L = 100,
+    maxit = 1000), against the reference's own two runs (tests/golden/lindep_dense_n1200.npz).  The solves are
+    deliberately sloppy, so the comparison is on what the reference's test reads: the status fields and the count of
+    returned vectors; the converged Ritz values agree to the accuracy the run itself reached."""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from make_golden_r2 import lindep_case, LINDEP
+    g = load_golden("lindep_dense_n1200.npz")
+    A, y0 = lindep_case()
+    H = hip.HipCsrOperator.from_dense(A)
+    opt = lambda: {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": LINDEP["linearIter"], "linear_tol": LINDEP["linear_tol"]}}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ev, Y, st = hip.inexactLanczosDiagonalization(H, hip.HipVector(y0.copy(), opt()), LINDEP["sigma"], LINDEP["L"], LINDEP["maxit"],
+                                                      1e-12, writeOut=False)
+    assert st["isConverged"] and not st["lindep"] and st["outerIter"] == 0 and st["futileRestarts"] == 0
+    assert abs(st["cumIter"] - int(g["cumIter_a"])) <= 2 and len(Y) == st["cumIter"] + 1
+    np.testing.assert_allclose(ev[:3], g["ev_a"][:3], rtol=1e-9)
+    exact = np.linspace(1, 400, 1200)
+    assert abs(ev[0] - exact[np.argmin(np.abs(exact - 390))]) < 1e-6
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ev, Y, st = hip.inexactLanczosDiagonalization(H, hip.HipVector(y0.copy(), opt()), LINDEP["sigma"], LINDEP["L"], LINDEP["maxit"],
+                                                      1e-18, writeOut=False)
+    # the reference: cycle exhausted (cumIter = L), one restart, NaN Ritz values, one vector back
+    assert (st["outerIter"], st["cumIter"], st["isConverged"]) == (int(g["outerIter_b"]), int(g["cumIter_b"]), False)
+    assert np.all(np.isnan(ev)) and len(Y) == int(g["nvec_b"]) == st["innerIter"]

@@ -49,6 +49,39 @@ def test_block3_degenerate_matches_reference():
     np.testing.assert_allclose(e[:3], g["exact"][5:8], rtol=1e-6)
 
 
+def test_lindep_test_case_matches_reference():
+    """unittests/test_lanczosLINDEP.py:9-58 (dense n = 1200, gcrotmk rtol 1e-1, L = 100): both runs of the reference,
+    through the oracle AND through the product's host driver on the oracle's vector class - Ritz values and every
+    status field the reference's test reads.  With eConv = 1e-12 the run converges inside the first cycle (the
+    reference's own comment: the lindep assertion 'may fail on some machines'); with 1e-18 it exhausts the cycle,
+    restarts and ends with NaN Ritz values and ONE returned vector."""
+    import os, sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from make_golden_r2 import lindep_case, LINDEP, STATUS_KEYS
+    import eigensolvers_amd as ea
+    ea.AbstractVector.register(RefVector)
+    g = load_golden("lindep_dense_n1200.npz")
+    A, y0 = lindep_case()
+    for tag in ("a", "b"):
+        econv = float(g[f"eConv_{tag}"])
+        for run in (lambda v: lanczos_ref.inexact_lanczos(A, v, LINDEP["sigma"], LINDEP["L"], LINDEP["maxit"], econv),
+                    lambda v: ea.inexactLanczosDiagonalization(A, v, LINDEP["sigma"], LINDEP["L"], LINDEP["maxit"], econv, writeOut=False)):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                e, Y, st = run(RefVector(y0.copy(), _opts("gcrotmk", LINDEP["linearIter"], LINDEP["linear_tol"])))
+            _same(np.asarray(e, dtype=float), g[f"ev_{tag}"], 1e-9)
+            assert len(Y) == int(g[f"nvec_{tag}"])
+            for k in STATUS_KEYS:
+                if k == "residual":
+                    assert st[k] == pytest.approx(float(g[f"residual_{tag}"]), rel=1e-3, abs=1e-15)
+                else:
+                    assert st[k] == g[f"{k}_{tag}"].item(), (tag, k)
+    # the reference test's own assertions (:43-58): vectors returned == innerIter where lindep fired, futile restarts
+    # counted only when the run stopped before maxit
+    assert int(g["nvec_b"]) == int(g["innerIter_b"])
+
+
 @pytest.mark.parametrize("solver", ["minres", "gcrotmk"])
 def test_gapped_csr_matches_reference(gapped4000, solver):
     H, guess = gapped4000
