@@ -65,6 +65,18 @@ def test_feast_reference_problem_on_device(hip):
     np.testing.assert_allclose(found, pf.select_within_range(g["ev"], 160.0, 166.0)[0], rtol=1e-6)
     S = hip.HipVector.overlapMatrix(Yf)
     np.testing.assert_allclose(S, np.eye(len(Yf)), atol=1e-5)
+    # test_feast.py "back-transform" and "transformationMatrix" sub-tests (:73-104): Loewdin + Ritz of the returned basis
+    # give a transformation X with X^H S X = 1, and the transformed vectors are the returned ones up to a sign
+    from eigensolvers_amd.subspace import basisTransformation, loewdin_transform, ritz_pairs
+    Hm = hip.HipVector.matrixRepresentation(H, Yf)
+    uS = loewdin_transform(S)[1]
+    uSH = uS @ ritz_pairs(uS, Hm)[1]
+    np.testing.assert_allclose(uSH.T.conj() @ S @ uSH, np.eye(uSH.shape[1]), atol=1e-5)
+    bases = basisTransformation(Yf, uSH)
+    for m in range(len(Yf)):
+        ov = bases[m].vdot(Yf[m], True)
+        assert abs(abs(ov) - 1) < 1e-5
+        np.testing.assert_allclose(Yf[m].array, ov * bases[m].array, atol=1e-5)
     # eigenvectors of the in-window states (test_feast.py::test_eigenvector, rtol 1e-2)
     w, V = np.linalg.eigh(A)
     for e in inside:
