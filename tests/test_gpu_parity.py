@@ -404,8 +404,8 @@ def test_lanczos_checkpoint_resume_and_thick_restart_on_device(hip, gapped4000, 
 
 
 def test_lanczos_dense_reference_test_case(hip):
-    """unittests/test_lanczos.py restated for HipVector (the dense matrix stored as full CSR,
-    MINRES as inner solver since GCROT is not on the device yet)."""
+    """unittests/test_lanczos.py restated for HipVector with MINRES as the inner solver (the dense matrix stored
+    as full CSR); the like-for-like gcrotmk run is test_reference_unit_tests_with_gcrotmk_on_device."""
     g = load_golden("lanczos_n100_seed1212.npz")
     A, exact = dense_test_matrix(100, 1212)
     H = hip.HipCsrOperator.from_dense(A)
@@ -591,6 +591,25 @@ def test_reference_unit_tests_with_gcrotmk_on_device(hip):
     assert st["cumIter"] == int(g["cumIter"]) and st["isConverged"]
     np.testing.assert_allclose(ev[:2], g["ev"], rtol=1e-6)
     assert abs(hip.find_nearest(ev, 30)[1] - hip.find_nearest(exact, 30)[1]) <= 1e-4
+    # the remaining sub-tests of test_lanczos.py:44-91 on the returned device vectors
+    from eigensolvers_amd.subspace import loewdin_transform, ritz_pairs
+    Hd = hip.HipCsrOperator.from_dense(A)
+    assert isinstance(ev, np.ndarray) and isinstance(Y, list) and isinstance(Y[0], hip.HipVector)          # "returnType"
+    S = hip.HipVector.overlapMatrix(Y)
+    np.testing.assert_allclose(S, np.eye(len(Y)), atol=1e-5)                                               # "orthogonal"
+    Hm = hip.HipVector.matrixRepresentation(Hd, Y)
+    uS = loewdin_transform(S)[1]
+    uSH = uS @ ritz_pairs(uS, Hm)[1]
+    np.testing.assert_allclose(uSH.T.conj() @ S @ uSH, np.eye(uSH.shape[1]), atol=1e-5)                    # "transformationMatrix"
+    np.testing.assert_allclose(hip.HipVector.extendOverlapMatrix(Y, hip.HipVector.overlapMatrix(Y[:-1])), S, atol=1e-9)   # "extension"
+    np.testing.assert_allclose(hip.HipVector.extendMatrixRepresentation(Hd, Y, hip.HipVector.matrixRepresentation(Hd, Y[:-1])),
+                               Hm, atol=1e-9)
+    w1, V1 = np.linalg.eigh(A)
+    exact_vec = V1[:, hip.find_nearest(w1, 30)[0]]                                                         # "eigenvector"
+    lan_vec = Y[hip.find_nearest(ev, 30)[0]].array
+    ov = np.vdot(exact_vec, lan_vec)
+    np.testing.assert_allclose(abs(ov), 1, rtol=1e-5)
+    np.testing.assert_allclose(exact_vec, lan_vec * ov, rtol=1e-5, atol=1e-4)
     gb = load_golden("block3_degenerate.npz")
     Ab, _ = dense_test_matrix(100, 1212, gb["exact"])
     v0 = [hip.HipVector(gb["guess"][:, i].copy(), opt()) for i in range(3)]
