@@ -107,6 +107,14 @@ def main(result):
     barrier()
     wall = allmax(time.perf_counter() - t0)
     dev_ms = allmax(dev_ms)
+    # spread of single steps (median + min), measured AFTER the timed region, one event pair per step
+    singles = []
+    for _ in range(min(a.steps, 20)):
+        ctx.timer_start()
+        H.apply_shifted(a.sigma, x._buf, y)
+        singles.append(ctx.timer_stop())
+    singles.sort()
+    step_median, step_min = allmax(singles[len(singles) // 2]), allmax(singles[0])
 
     gbytes = global_bytes(N, nnz_total) / 1e9
     value = gbytes * a.steps / wall
@@ -143,7 +151,8 @@ def main(result):
                      "launches_per_step": nlaunch,
                      "algorithmic_bytes_per_launch": int(H.algorithmic_bytes() // nlaunch),
                      "avg_launch_ms": round(dev_ms / a.steps / nlaunch, 5),
-                     "ms_per_step_device": round(dev_ms / a.steps, 5)},
+                     "ms_per_step_device": round(dev_ms / a.steps, 5),
+                     "single_step_ms_median": round(step_median, 5), "single_step_ms_min": round(step_min, 5)},
     }
 
     # ---- Lanczos iterations/s on the same operator (outside the timed SpMV region) ----
