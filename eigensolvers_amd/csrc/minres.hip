@@ -234,8 +234,18 @@ __global__ void minres_check_kernel(MinresArgs a, MinresState* __restrict__ S0) 
   if (threadIdx.x == 0) *S0 = S;
 }
 
+extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, double sign, const double* b, const double* x0,
+                                double* x, double rtol, int maxiter, int* info, double out_stats[8]);
+
 extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double sign, const double* b,
                              double* x, double rtol, int maxiter, int* info, double out_stats[8]) {
+  return hipeig_minres_x0(c, A, sigma, sign, b, nullptr, x, rtol, maxiter, info, out_stats);
+}
+
+// x0 != NULL: SciPy's minres(A, b, x0) - r1 = b - A x0, the iterate starts at x0 (so ||x|| in the stopping tests
+// includes it), beta1 = ||r1||; beta1 == 0 returns x0, b == 0 returns b (scipy.sparse.linalg.minres, the x0 branch).
+extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, double sign, const double* b, const double* x0,
+                                double* x, double rtol, int maxiter, int* info, double out_stats[8]) {
   HIPEIG_REQUIRE(info != nullptr, "null info");
   HIPEIG_REQUIRE(sign == 1.0 || sign == -1.0, "sign must be +1 or -1");
   HIPEIG_REQUIRE(maxiter >= 1, "maxiter must be positive");
@@ -246,7 +256,7 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   if (out_stats) memset(out_stats, 0, 8 * sizeof(double));
   double bb = 0.0;
   if (hipeig_dot(c, n, b, b, &bb)) return 1;
-  if (bb == 0.0) return hipeig_vec_fill(c, x, n, 0.0);            // beta1 == 0: the exact solution is x0 = 0
+  if (bb == 0.0) return hipeig_vec_fill(c, x, n, 0.0);            // beta1 == 0 (or b == 0): the exact solution is x = 0 = b
 
   // workspace: R[3] (r1, r2, y rotate), W[3] (w1, w2, w rotate) and the iterate xw.  The iterate
   // lives in the workspace so that every kernel argument of a chunk is the same from solve to
@@ -262,8 +272,19 @@ extern "C" int hipeig_minres(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   double* R[3] = {c->mr_ws, c->mr_ws + npad, c->mr_ws + 2 * npad};
   double* W[3] = {c->mr_ws + 3 * npad, c->mr_ws + 4 * npad, c->mr_ws + 5 * npad};
   double* xw = c->mr_ws + 6 * npad;
-  HIPEIG_CHECK(hipMemcpyAsync(R[0], b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPEIG_CHECK(hipMemsetAsync(W[0], 0, (size_t)npad * 4 * sizeof(double), c->stream));   // W[0..2] and xw
+  if (x0) {
+    if (hipeig_spmv_shift(c, A, sigma, sign, x0, R[0])) return 1;          // A x0 with the two roundings of the lambda
+    if (hipeig_axpby(c, n, 1.0, b, -1.0, R[0])) return 1;                  // r1 = b - A x0
+    if (hipeig_dot(c, n, R[0], R[0], &bb)) return 1;
+    if (bb == 0.0) {                                                        // beta1 == 0: x0 is the exact solution
+      if (x != x0) HIPEIG_CHECK(hipMemcpyAsync(x, x0, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      return 0;
+    }
+    HIPEIG_CHECK(hipMemcpyAsync(xw, x0, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  } else {
+    HIPEIG_CHECK(hipMemcpyAsync(R[0], b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
 
   MinresState* h = c->h_mr_state;
   minres_init_state(h, bb);

@@ -216,7 +216,7 @@ def _fgmres(ops, matvec, v0, m, atol, cs):
     return Q, R, B[:, :j + 1], vs, y, res
 
 
-def gcrotmk_device(ctx, matvec, b, n, rtol=1e-5, atol=0.0, maxiter=1000, m=20, k=None, complex_pairs=False):
+def gcrotmk_device(ctx, matvec, b, n, rtol=1e-5, atol=0.0, maxiter=1000, m=20, k=None, complex_pairs=False, x0=None):
     """Solve A x = b; ``matvec(buf) -> new buf`` applies A on the device.
 
     With ``complex_pairs`` the vectors are (re, im) pairs of device buffers and the arithmetic is
@@ -225,12 +225,18 @@ def gcrotmk_device(ctx, matvec, b, n, rtol=1e-5, atol=0.0, maxiter=1000, m=20, k
     ops = _PairOps(ctx, n) if complex_pairs else _Ops(ctx, n)
     if k is None:
         k = m
-    if complex_pairs:
-        x = ops.zeros()
+    if x0 is not None:                                 # SciPy: x = x0, r = b - A x0
+        x = ops.copy(x0)
+        r = matvec(x)
+        ops.scal(-1.0, r)
+        ops.axpy(1.0, b, r)
     else:
-        x = ops.new()
-        _lib.call("hipeig_vec_fill", ctx.handle, x.ptr, n, 0.0)
-    r = ops.copy(b)
+        if complex_pairs:
+            x = ops.zeros()
+        else:
+            x = ops.new()
+            _lib.call("hipeig_vec_fill", ctx.handle, x.ptr, n, 0.0)
+        r = ops.copy(b)
     b_norm = ops.nrm2(b)
     if not np.isfinite(b_norm):
         raise ValueError("RHS must contain only finite numbers")

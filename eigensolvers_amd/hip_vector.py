@@ -483,12 +483,14 @@ class HipVector(AbstractVector):
     def solve(H, b, sigma, x0=None, opType="her", reverseGF=False):
         if not isinstance(H, HipCsrOperator):
             raise TypeError("HipVector.solve needs a HipCsrOperator (device-resident CSR)")
-        if x0 is not None:
-            raise NotImplementedError("HipVector.solve starts from a zero guess (the Lanczos path passes none)")
+        if x0 is not None and not isinstance(x0, HipVector):
+            x0 = HipVector(np.asarray(x0, dtype=np.float64), ctx=b.ctx)      # NumpyVector hands an ndarray on to SciPy
         H.honour_reduction_option(b.options)
         o = b.options["linearSystemArgs"]
         name = o["linearSolver"]
         if isinstance(sigma, complex) or np.iscomplexobj(sigma):
+            if x0 is not None:
+                raise NotImplementedError("a complex shift starts from a zero guess (feast.py:90-97 passes none)")
             return HipVector._solve_complex(H, b, complex(sigma), o, reverseGF)
         if name == "gcrotmk":
             # numpyVector.py:161: gcrotmk(linOp, b, x0, tol, atol, maxiter) with SciPy's m = k = 20
@@ -500,7 +502,8 @@ class HipVector(AbstractVector):
                 return out
 
             xbuf, conv, gstats = gcrotmk_device(b.ctx, matvec, b._buf, b._buf.n, rtol=float(o["linear_tol"]),
-                                                atol=float(o["linear_atol"]), maxiter=int(o["linearIter"]))
+                                                atol=float(o["linear_atol"]), maxiter=int(o["linearIter"]),
+                                                x0=None if x0 is None else x0._buf)
             res = b._new(xbuf)
             res.last_solve_stats = b.last_solve_stats = {"iterations": gstats["matvecs"], "outer": gstats["outer"]}
             if conv != 0:
@@ -513,8 +516,12 @@ class HipVector(AbstractVector):
         out = b.ctx.alloc(b._buf.n)
         info = C.c_int()
         stats = (C.c_double * 8)()
-        _lib.call("hipeig_minres", b.ctx.handle, H.handle, float(sigma), -1.0 if reverseGF else 1.0,
-                  b._buf.ptr, out.ptr, float(o["linear_tol"]), int(o["linearIter"]), C.byref(info), stats)
+        if x0 is None:
+            _lib.call("hipeig_minres", b.ctx.handle, H.handle, float(sigma), -1.0 if reverseGF else 1.0,
+                      b._buf.ptr, out.ptr, float(o["linear_tol"]), int(o["linearIter"]), C.byref(info), stats)
+        else:               # scipy.sparse.linalg.minres(linOp, b, x0): r1 = b - A x0, the iterate starts at x0
+            _lib.call("hipeig_minres_x0", b.ctx.handle, H.handle, float(sigma), -1.0 if reverseGF else 1.0,
+                      b._buf.ptr, x0._buf.ptr, out.ptr, float(o["linear_tol"]), int(o["linearIter"]), C.byref(info), stats)
         res = b._new(out)
         res.last_solve_stats = {"iterations": int(stats[0]), "istop": int(stats[1]), "rnorm": stats[2],
                                 "Anorm": stats[3], "ynorm": stats[4], "test1": stats[5],

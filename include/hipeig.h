@@ -199,6 +199,12 @@ int hipeig_csr_block_info(hipeig_csr* A, int64_t info[4]);
  * *info follows SciPy: maxiter if the iteration limit was hit (istop==6) else 0.         */
 int hipeig_minres(hipeig_ctx* ctx, hipeig_csr* A, double sigma, double sign, const double* b,
                   double* x, double rtol, int maxiter, int* info, double out_stats[8]);
+/* The same with SciPy's initial guess (numpyVector.py:163 hands x0 on to scipy.sparse.linalg.minres): r1 = b - A x0,
+ * the iterate starts at x0.  x0 == NULL is hipeig_minres.  The reference's solvers never pass one
+ * (inexact_Lanczos.py:99, feast.py:90-97); the parameter is part of NumpyVector.solve's signature.            */
+int hipeig_minres_x0(hipeig_ctx* ctx, hipeig_csr* A, double sigma, double sign, const double* b,
+                     const double* x0, double* x, double rtol, int maxiter, int* info,
+                     double out_stats[8]);
 
 /* The nBlock solves of one block-Lanczos iteration (inexact_Lanczos.py:319-320: one NumpyVector.solve
  * per block vector, same operator, same shift) advanced in lock step: k <= 8 right-hand sides, ONE block

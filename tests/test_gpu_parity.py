@@ -652,3 +652,45 @@ def test_reference_lindep_test_case_on_device(hip):
     # the reference: cycle exhausted (cumIter = L), one restart, NaN Ritz values, one vector back
     assert (st["outerIter"], st["cumIter"], st["isConverged"]) == (int(g["outerIter_b"]), int(g["cumIter_b"]), False)
     assert np.all(np.isnan(ev)) and len(Y) == int(g["nvec_b"]) == st["innerIter"]
+
+
+def test_solve_with_an_initial_guess_tracks_scipy(hip, gapped4000):
+    """``solve(H, b, sigma, x0)``: NumpyVector hands x0 on to SciPy (numpyVector.py:161,163).  The reference's solvers
+    never pass one, so there is no golden run; the check is against scipy.sparse.linalg itself on the same operator
+    (the third-party routine the reference calls): MINRES iteration count equal, iterates to the solve tolerance;
+    an exact x0 is returned at once; GCROT converges from x0 to the same solution."""
+    import scipy.sparse.linalg as spla
+    Hh, guess = gapped4000
+    n = Hh.shape[0]
+    H = hip.HipCsrOperator.from_scipy(Hh)
+    rng = np.random.default_rng(21)
+    b = guess / np.linalg.norm(guess)
+    x0 = 0.3 * rng.standard_normal(n)
+    lin = spla.LinearOperator((n, n), matvec=lambda v: 0.02 * v - Hh @ v, dtype=np.float64)
+    for rtol in (1e-6, 1e-10):
+        its = []
+        ref, info = spla.minres(lin, b, x0, rtol=rtol, maxiter=2000, callback=lambda xk: its.append(1))
+        assert info == 0
+        W = hip.HipVector.solve(H, hip.HipVector(b.copy(), _opts(2000, rtol)), 0.02, hip.HipVector(x0.copy()))
+        assert W.last_solve_stats["iterations"] == len(its)
+        assert np.linalg.norm(W.array - ref) <= max(1e-9, 10 * rtol) * np.linalg.norm(ref)
+        W2 = hip.HipVector.solve(H, hip.HipVector(b.copy(), _opts(2000, rtol)), 0.02, x0.copy())       # ndarray guess, as NumpyVector takes it
+        np.testing.assert_array_equal(W2.array, W.array)
+    # reverseGF flips the operator's sign (numpyVector.py:153-154)
+    linr = spla.LinearOperator((n, n), matvec=lambda v: Hh @ v - 0.02 * v, dtype=np.float64)
+    ref, info = spla.minres(linr, b, x0, rtol=1e-8, maxiter=2000)
+    W = hip.HipVector.solve(H, hip.HipVector(b.copy(), _opts(2000, 1e-8)), 0.02, hip.HipVector(x0.copy()), reverseGF=True)
+    assert np.linalg.norm(W.array - ref) <= 1e-7 * np.linalg.norm(ref)
+    # an exact initial guess: beta1 = 0, x0 comes back untouched, no iteration
+    xe = hip.HipVector(rng.standard_normal(n))
+    buf = hip.HipContext.default().alloc(n)
+    H.apply_shifted(0.02, xe._buf, buf)                         # b = A xe as the device evaluates it: r1 = b - A xe = 0 exactly
+    We = hip.HipVector.solve(H, hip.HipVector(buf, _opts(2000, 1e-10)), 0.02, xe)
+    assert We.last_solve_stats["iterations"] == 0
+    np.testing.assert_array_equal(We.array, xe.array)
+    # GCROT from x0
+    og = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 1000, "linear_tol": 1e-9, "linear_atol": 1e-12}}
+    refg, infog = spla.gcrotmk(lin, b, x0, rtol=1e-9, atol=1e-12, maxiter=1000)
+    Wg = hip.HipVector.solve(H, hip.HipVector(b.copy(), og), 0.02, hip.HipVector(x0.copy()))
+    assert infog == 0 and np.linalg.norm(Wg.array - refg) <= 1e-7 * np.linalg.norm(refg)
+    assert np.linalg.norm(0.02 * Wg.array - Hh @ Wg.array - b) <= 2e-9
