@@ -389,8 +389,11 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
   _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j) {                            \
     const uint32_t q = (BASE) + lane + jstride * j;                                         \
     const bool ok = q < send;                                                          \
-    ID[j] = ok ? __builtin_nontemporal_load(T.idx + q) : 0xFFFFFFFFu;                  \
-    V[j] = (ok && !(TCOO_ABL(T, 4))) ? __builtin_nontemporal_load(T.val + q) : 1.0;     \
+    /* experiment bit 16: the stream re-reads the unit's first 4096 elements (L2-resident stream: what a perfect */ \
+    /* prefetch of the stream into L2 could buy; wrong results)                                                  */ \
+    const uint32_t ql = (TCOO_ABL(T, 16)) ? sbeg + ((q - sbeg) & 4095u) : q;           \
+    ID[j] = ok ? __builtin_nontemporal_load(T.idx + ql) : 0xFFFFFFFFu;                 \
+    V[j] = (ok && !(TCOO_ABL(T, 4))) ? __builtin_nontemporal_load(T.val + ql) : 1.0;    \
   }
 #define TCOO_CONSUME(ID, V, BASE)                                                      \
   {                                                                                    \
