@@ -20,6 +20,16 @@ def _free_port():
     return p
 
 
+def _one_blas_thread():
+    """Several ranks on the container's 8 cores: one BLAS thread each (n = 100 .. 1500 gains nothing from more, and the
+    oversubscribed pools cost tens of seconds)."""
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+
+
 def _worker(rank, world, port, N, out_dir):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -91,6 +101,7 @@ def _feast_worker(rank, world, port, out_dir):
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    _one_blas_thread()
     import eigensolvers_amd as ea
     from conftest import load_golden
     from eigensolvers_amd import distributed as D
