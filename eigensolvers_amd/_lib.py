@@ -76,6 +76,7 @@ SIGNATURES = {
     "hipeig_spmm": [_P, _P, C.c_int, _PP, _PP],
     "hipeig_minres": [_P, _P, _D, _D, _P, _P, _D, C.c_int, _IP, _DP],
     "hipeig_minres_x0": [_P, _P, _D, _D, _P, _P, _P, _D, C.c_int, _IP, _DP],
+    "hipeig_dense_solve_small": [_P, _P, _D, _D, _D, _P, _P, _P, _P, _IP],
     "hipeig_minres_block": [_P, _P, _D, _D, C.c_int, _PP, _PP, _D, C.c_int, _IP, _DP],
     "hipeig_csr_set_block_variant": [_P, C.c_int],
     "hipeig_csr_block_info": [_P, _I64P],

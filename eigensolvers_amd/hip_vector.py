@@ -488,6 +488,8 @@ class HipVector(AbstractVector):
         H.honour_reduction_option(b.options)
         o = b.options["linearSystemArgs"]
         name = o["linearSolver"]
+        if name == "pardiso":
+            return HipVector._solve_exact_small(H, b, sigma, reverseGF)
         if isinstance(sigma, complex) or np.iscomplexobj(sigma):
             if x0 is not None:
                 raise NotImplementedError("a complex shift starts from a zero guess (feast.py:90-97 passes none)")
@@ -510,8 +512,6 @@ class HipVector(AbstractVector):
                 raise UserWarning("Warning:: Iterative solver is not converged ")
             return res
         if name != "minres":
-            if name == "pardiso":
-                raise NotImplementedError("linearSolver='pardiso' (dense LU, Fortran comparison only) is host-only")
             raise Exception("Got linear solver other than gcrotmk, minres and pardiso!")
         out = b.ctx.alloc(b._buf.n)
         info = C.c_int()
@@ -582,6 +582,33 @@ class HipVector(AbstractVector):
             if any(info[j] != 0 for j in range(k)):
                 raise UserWarning("Warning:: Iterative solver is not converged ")
         return results
+
+    EXACT_SOLVE_MAX = 96
+
+    @staticmethod
+    def _solve_exact_small(H, b, sigma, reverseGF):
+        """``linearSolver="pardiso"`` (numpyVector.py:166-170: ``spsolve`` of ``sigma*I - H``, which the reference keeps
+        "only for comparing with fortran"): Gaussian elimination with partial pivoting on the device, one workgroup,
+        n <= 96.  Real or complex shift, real or complex right-hand side; never a CPU detour."""
+        ctx, n = b.ctx, len(b)
+        if n > HipVector.EXACT_SOLVE_MAX:
+            raise NotImplementedError(f"linearSolver='pardiso' is the reference's small exact branch (Fortran comparison); "
+                                      f"on the device it takes n <= {HipVector.EXACT_SOLVE_MAX}, got n = {n}")
+        z = complex(sigma)
+        cplx_b = isinstance(b, HipComplexVector)
+        br = b.re if cplx_b else b
+        bi = b.im._buf.ptr if cplx_b else None
+        is_complex = cplx_b or z.imag != 0.0 or isinstance(sigma, complex) or np.iscomplexobj(sigma)
+        xr = ctx.alloc(n)
+        xi = ctx.alloc(n) if is_complex else None
+        flag = C.c_int()
+        _lib.call("hipeig_dense_solve_small", ctx.handle, H.handle, z.real, z.imag, -1.0 if reverseGF else 1.0,
+                  br._buf.ptr, bi, xr.ptr, None if xi is None else xi.ptr, C.byref(flag))
+        if flag.value:
+            raise np.linalg.LinAlgError("sigma*I - H is singular to working precision")
+        res = HipComplexVector(br._new(xr), br._new(xi)) if is_complex else br._new(xr)
+        res.last_solve_stats = b.last_solve_stats = {"iterations": 0, "exact": True}
+        return res
 
     @staticmethod
     def _solve_complex(H, b, z, o, reverseGF):
@@ -821,6 +848,8 @@ class HipComplexVector(AbstractVector):
         if x0 is not None:
             raise NotImplementedError("solve starts from a zero guess (the solvers pass none)")
         o = b.options["linearSystemArgs"]
+        if o["linearSolver"] == "pardiso":
+            return HipVector._solve_exact_small(H, b, sigma, reverseGF)
         is_complex_shift = isinstance(sigma, complex) or np.iscomplexobj(sigma)
         if o["linearSolver"] == "minres" and not is_complex_shift:
             xr, xi = HipVector.solveBlock(H, [b.re, b.im], sigma, reverseGF=reverseGF)

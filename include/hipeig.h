@@ -206,6 +206,14 @@ int hipeig_minres_x0(hipeig_ctx* ctx, hipeig_csr* A, double sigma, double sign, 
                      const double* x0, double* x, double rtol, int maxiter, int* info,
                      double out_stats[8]);
 
+/* linearSolver = "pardiso" (numpyVector.py:166-170: spsolve of sigma*I - H, kept by the reference "only for comparing
+ * with fortran" - the 4 x 4 known-answer system of unittests/test_feast_fortran.py): x = (sign*(z I - H))^-1 b by
+ * Gaussian elimination with partial pivoting in the LDS of one workgroup, n <= 96, z = zr + i zi.  b_im and x_im may be
+ * NULL for a real system (zi == 0).  *singular != 0: a zero pivot column, x is not written.                    */
+int hipeig_dense_solve_small(hipeig_ctx* ctx, hipeig_csr* A, double zr, double zi, double sign,
+                             const double* b_re, const double* b_im, double* x_re, double* x_im,
+                             int* singular);
+
 /* The nBlock solves of one block-Lanczos iteration (inexact_Lanczos.py:319-320: one NumpyVector.solve
  * per block vector, same operator, same shift) advanced in lock step: k <= 8 right-hand sides, ONE block
  * product per iteration.  Column j runs exactly the recurrences and stopping tests of hipeig_minres on

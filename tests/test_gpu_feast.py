@@ -84,6 +84,50 @@ def test_feast_reference_problem_on_device(hip):
         assert abs(abs(np.vdot(V[:, hip.find_nearest(w, e)[0]], vec)) - 1) < 1e-2
 
 
+def test_exact_branch_pardiso_on_the_fortran_system_and_beyond(hip):
+    """``linearSolver="pardiso"`` (numpyVector.py:166-170), the branch unittests/test_feast_fortran.py:85-117 runs: an exact
+    solve of (z I - H) x = b.  On the device it is Gaussian elimination with partial pivoting in one workgroup (n <= 96).
+    The Fortran known answers to the reference's rtol 1e-5, and dense systems up to the size limit against numpy.linalg."""
+    A, Y1 = read_fortran()[:2]
+    H = hip.HipCsrOperator.from_dense(A)
+    par = lambda: {"linearSystemArgs": {"linearSolver": "pardiso"}}
+    guess = [hip.HipVector(Y1[i, :].real.copy(), par()) for i in range(3)]
+    gk, wk = pf.quadraturePointsWeights(8, "legendre", positiveHalf=False)
+    theta = (-(np.pi * 0.5) * (gk - 1))[ORDER]
+    wk = wk[ORDER]
+    Q = [None] * 3
+    for k in range(8):
+        fQe, fQ = read_fortran(k)[6:8]
+        z = 4.0 + math.cos(theta[k]) + 0.3j * math.sin(theta[k])
+        for i in range(3):
+            Qe = hip.HipVector.solve(H, guess[i], z, opType="gen")
+            assert isinstance(Qe, hip.hip_vector.HipComplexVector) and Qe.last_solve_stats["exact"]
+            np.testing.assert_allclose(Qe.array, fQe[i], rtol=1e-5)                 # test_Qe
+            np.testing.assert_allclose(Qe.array, np.linalg.solve(z * np.eye(4) - A, Y1[i, :].real), rtol=1e-13)
+            Q = pf.updateQ(Q, i, pf.calculateQuadrature(H, guess[i], z, 1.0, theta[k], wk[k], 0.3), k)
+        for i in range(3):
+            np.testing.assert_allclose(Q[i].array, fQ[i], rtol=1e-5)                # test_Q
+    rng = np.random.default_rng(17)
+    for n in (1, 2, 37, 96):
+        B = rng.standard_normal((n, n)); B = B + B.T
+        Hn = hip.HipCsrOperator.from_dense(B)
+        b = rng.standard_normal(n)
+        xr = hip.HipVector.solve(Hn, hip.HipVector(b.copy(), par()), 0.37)                               # real shift: real result
+        assert isinstance(xr, hip.HipVector) and not isinstance(xr, hip.hip_vector.HipComplexVector)
+        np.testing.assert_allclose(xr.array, np.linalg.solve(0.37 * np.eye(n) - B, b), rtol=1e-9, atol=1e-12)
+        xg = hip.HipVector.solve(Hn, hip.HipVector(b.copy(), par()), 0.37, reverseGF=True)               # H - sigma (numpyVector.py:168-169)
+        np.testing.assert_allclose(xg.array, -xr.array, rtol=1e-12, atol=1e-14)
+        z = 0.37 + 0.8j
+        bc = b + 1j * rng.standard_normal(n)
+        xc = hip.HipVector.solve(Hn, hip.HipVector(bc.copy(), par()), z)                                 # complex right-hand side
+        np.testing.assert_allclose(xc.array, np.linalg.solve(z * np.eye(n) - B, bc), rtol=1e-10, atol=1e-13)
+    with pytest.raises(NotImplementedError):                                                             # the size limit is loud
+        big = hip.HipCsrOperator.from_dense(np.eye(97))
+        hip.HipVector.solve(big, hip.HipVector(np.ones(97), par()), 0.5)
+    with pytest.raises(np.linalg.LinAlgError):                                                           # singular: sigma is an eigenvalue
+        hip.HipVector.solve(hip.HipCsrOperator.from_dense(np.diag([1.0, 2.0, 3.0])), hip.HipVector(np.ones(3), par()), 2.0)
+
+
 # ---------------------------------------------------------------- complex128 input vectors (numpyVector.py:89-93)
 def test_complex_vectors_match_the_ndarray_backend(hip, gapped4000):
     """``HipVector(complex array)`` gives a complex device vector (two real halves) with the semantics of a

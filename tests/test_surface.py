@@ -66,7 +66,7 @@ def test_hip_vector_has_numpy_vectors_signatures():
         # (typeClass.f(...)); a staticmethod is callable the same way
         assert got == spec["params"], f"{name}: {got} != {spec['params']}"
     extra = {n for n in vars(HipVector) if not n.startswith("_")} - set(ref)
-    assert extra <= {"fromArray", "array", "linearCombinationBlock", "solveBlock", "BLOCK_SOLVE_MIN"}, extra
+    assert extra <= {"fromArray", "array", "linearCombinationBlock", "solveBlock", "BLOCK_SOLVE_MIN", "EXACT_SOLVE_MAX"}, extra
 
 
 def test_solver_entry_points_accept_the_reference_arguments():
