@@ -483,17 +483,19 @@ class HipVector(AbstractVector):
     def solve(H, b, sigma, x0=None, opType="her", reverseGF=False):
         if not isinstance(H, HipCsrOperator):
             raise TypeError("HipVector.solve needs a HipCsrOperator (device-resident CSR)")
-        if x0 is not None and not isinstance(x0, HipVector):
-            x0 = HipVector(np.asarray(x0, dtype=np.float64), ctx=b.ctx)      # NumpyVector hands an ndarray on to SciPy
+        if isinstance(b, HipComplexVector):                 # HipVector(complex array) is a HipComplexVector: same entry point
+            return HipComplexVector.solve(H, b, sigma, x0, opType, reverseGF)
+        if x0 is not None and not isinstance(x0, (HipVector, HipComplexVector)):
+            x0 = HipVector(np.asarray(x0), ctx=b.ctx)      # NumpyVector hands an ndarray on to SciPy; complex arrays become HipComplexVector
+        if isinstance(x0, HipComplexVector) and not (isinstance(sigma, complex) or np.iscomplexobj(sigma)):
+            return HipComplexVector.solve(H, HipComplexVector(b, b * 0.0), sigma, x0, opType, reverseGF)    # a complex guess makes the solve complex
         H.honour_reduction_option(b.options)
         o = b.options["linearSystemArgs"]
         name = o["linearSolver"]
         if name == "pardiso":
             return HipVector._solve_exact_small(H, b, sigma, reverseGF)
         if isinstance(sigma, complex) or np.iscomplexobj(sigma):
-            if x0 is not None:
-                raise NotImplementedError("a complex shift starts from a zero guess (feast.py:90-97 passes none)")
-            return HipVector._solve_complex(H, b, complex(sigma), o, reverseGF)
+            return HipVector._solve_complex(H, b, complex(sigma), o, reverseGF, x0)
         if name == "gcrotmk":
             # numpyVector.py:161: gcrotmk(linOp, b, x0, tol, atol, maxiter) with SciPy's m = k = 20
             from .gcrotmk import gcrotmk_device
@@ -611,7 +613,7 @@ class HipVector(AbstractVector):
         return res
 
     @staticmethod
-    def _solve_complex(H, b, z, o, reverseGF):
+    def _solve_complex(H, b, z, o, reverseGF, x0=None):
         """(z*I - H) x = b with a complex contour point z, real H and real b (feast.py:83-90).
         The system is complex symmetric, so the reference uses GCROT there; the complex vectors
         are (re, im) pairs of device buffers and one complex product costs two operator sweeps."""
@@ -637,9 +639,19 @@ class HipVector(AbstractVector):
             zero = ctx.alloc(n)
             _lib.call("hipeig_vec_fill", ctx.handle, zero.ptr, n, 0.0)
             rhs = (b._buf, zero)
+        guess = None
+        if x0 is not None:                              # SciPy's x0 (numpyVector.py:161): real or complex, array or vector
+            if not isinstance(x0, (HipVector, HipComplexVector)):
+                x0 = HipVector(np.asarray(x0), ctx=ctx)              # complex arrays come back as HipComplexVector
+            if isinstance(x0, HipComplexVector):
+                guess = (x0.re._buf, x0.im._buf)
+            else:
+                zero0 = ctx.alloc(n)
+                _lib.call("hipeig_vec_fill", ctx.handle, zero0.ptr, n, 0.0)
+                guess = (x0._buf, zero0)
         x, conv, gstats = gcrotmk_device(ctx, matvec, rhs, n, rtol=float(o["linear_tol"]),
                                          atol=float(o["linear_atol"]), maxiter=int(o["linearIter"]),
-                                         complex_pairs=True)
+                                         complex_pairs=True, x0=guess)
         res = HipComplexVector(b._new(x[0]), b._new(x[1]))
         res.last_solve_stats = b.last_solve_stats = {"iterations": gstats["matvecs"], "outer": gstats["outer"]}
         if conv != 0:
@@ -845,20 +857,25 @@ class HipComplexVector(AbstractVector):
         else is complex GCROT on (re, im) pairs, like a complex shift."""
         if not isinstance(H, HipCsrOperator):
             raise TypeError("HipComplexVector.solve needs a HipCsrOperator (device-resident CSR)")
-        if x0 is not None:
-            raise NotImplementedError("solve starts from a zero guess (the solvers pass none)")
         o = b.options["linearSystemArgs"]
         if o["linearSolver"] == "pardiso":
             return HipVector._solve_exact_small(H, b, sigma, reverseGF)
         is_complex_shift = isinstance(sigma, complex) or np.iscomplexobj(sigma)
+        if x0 is not None and not isinstance(x0, (HipVector, HipComplexVector)):
+            x0 = HipVector(np.asarray(x0), ctx=b.ctx)
         if o["linearSolver"] == "minres" and not is_complex_shift:
-            xr, xi = HipVector.solveBlock(H, [b.re, b.im], sigma, reverseGF=reverseGF)
+            if x0 is None:
+                xr, xi = HipVector.solveBlock(H, [b.re, b.im], sigma, reverseGF=reverseGF)
+            else:                                       # the real operator acts on the halves separately: so does the guess
+                g_re, g_im = (x0.re, x0.im) if isinstance(x0, HipComplexVector) else (x0, x0 * 0.0)
+                xr = HipVector.solve(H, b.re, sigma, g_re, reverseGF=reverseGF)
+                xi = HipVector.solve(H, b.im, sigma, g_im, reverseGF=reverseGF)
             res = HipComplexVector(xr, xi)
             res.last_solve_stats = b.last_solve_stats = {"re": xr.last_solve_stats, "im": xi.last_solve_stats,
                                                          "iterations": max(xr.last_solve_stats["iterations"],
                                                                            xi.last_solve_stats["iterations"])}
             return res
-        return HipVector._solve_complex(H, b, complex(sigma), o, reverseGF)
+        return HipVector._solve_complex(H, b, complex(sigma), o, reverseGF, x0)
 
     @staticmethod
     def _gram(A, B):

@@ -128,6 +128,35 @@ def test_exact_branch_pardiso_on_the_fortran_system_and_beyond(hip):
         hip.HipVector.solve(hip.HipCsrOperator.from_dense(np.diag([1.0, 2.0, 3.0])), hip.HipVector(np.ones(3), par()), 2.0)
 
 
+def test_complex_solves_from_an_initial_guess(hip, gapped4000):
+    """x0 on the complex paths (numpyVector.py:161,163 hand it to SciPy): complex shift + GCROT from a complex guess, and a
+    complex right-hand side with a real shift + MINRES (the halves take the halves of the guess) - against SciPy."""
+    import scipy.sparse.linalg as spla
+    Hh = gapped4000[0]
+    n = Hh.shape[0]
+    H = hip.HipCsrOperator.from_scipy(Hh)
+    rng = np.random.default_rng(4)
+    b = rng.standard_normal(n); b /= np.linalg.norm(b)
+    x0 = 0.2 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    z = 0.02 + 0.15j
+    lin = spla.LinearOperator((n, n), matvec=lambda v: z * v - Hh @ v, dtype=np.complex128)
+    ref, info = spla.gcrotmk(lin, b.astype(complex), x0, rtol=1e-9, atol=1e-12, maxiter=1000)
+    W = hip.HipVector.solve(H, hip.HipVector(b.copy(), _opts(1e-9, 1e-12)), z, x0)
+    assert info == 0 and isinstance(W, hip.hip_vector.HipComplexVector)
+    assert np.linalg.norm(W.array - ref) <= 1e-7 * np.linalg.norm(ref)
+    assert np.linalg.norm(z * W.array - Hh @ W.array - b) <= 2e-9
+    # starting AT the solution costs (almost) nothing
+    W2 = hip.HipVector.solve(H, hip.HipVector(b.copy(), _opts(1e-9, 1e-12)), z, W)
+    assert W2.last_solve_stats["iterations"] <= 2
+    bc = b + 1j * rng.standard_normal(n) / np.sqrt(n)
+    mo = {"linearSystemArgs": {"linearSolver": "minres", "linearIter": 3000, "linear_tol": 1e-10}}
+    linr = spla.LinearOperator((n, n), matvec=lambda v: 0.02 * v - Hh @ v, dtype=np.float64)
+    rr = spla.minres(linr, bc.real, x0.real, rtol=1e-10, maxiter=3000)[0]
+    ri = spla.minres(linr, bc.imag, x0.imag, rtol=1e-10, maxiter=3000)[0]
+    Wc = hip.HipVector.solve(H, hip.HipVector(bc.copy(), mo), 0.02, hip.HipVector(x0.copy()))
+    assert np.linalg.norm(Wc.array - (rr + 1j * ri)) <= 1e-8 * np.linalg.norm(rr + 1j * ri)
+
+
 # ---------------------------------------------------------------- complex128 input vectors (numpyVector.py:89-93)
 def test_complex_vectors_match_the_ndarray_backend(hip, gapped4000):
     """``HipVector(complex array)`` gives a complex device vector (two real halves) with the semantics of a
