@@ -73,6 +73,8 @@ SIGNATURES = {
     "hipeig_csr_fixed_info": [_P, _P, _DP],
     "hipeig_spmv": [_P, _P, _P, _P],
     "hipeig_spmv_shift": [_P, _P, _D, _D, _P, _P],
+    "hipeig_spmv_shift_pair": [_P, _P, _D, _D, _D, _P, _P, _P, _P],
+    "hipeig_csr_pair_info": [_P, _I64P],
     "hipeig_spmm": [_P, _P, C.c_int, _PP, _PP],
     "hipeig_minres": [_P, _P, _D, _D, _P, _P, _D, C.c_int, _IP, _DP],
     "hipeig_minres_x0": [_P, _P, _D, _D, _P, _P, _P, _D, C.c_int, _IP, _DP],

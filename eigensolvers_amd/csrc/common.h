@@ -113,6 +113,13 @@ struct hipeig_csr {
   uint32_t* w_off;
   int32_t w_nunits, w_nwin, w_wbits, w_rw, w_wgs_per_sweep;
   int32_t w_csplit;          // workgroups sharing one row block (column splits), 1 = none
+  // copy of the same layout for the pair sweep (two accumulators per row: units of half the rows), built
+  // on the first hipeig_spmv_shift_pair of a large operator
+  uint32_t* p_idx;
+  double* p_val;
+  uint32_t* p_off;
+  int32_t p_nunits, p_nwin, p_wbits, p_rw, p_wgs_per_sweep;
+  int32_t last_pair_fused;   // 1 when the most recent pair product ran as one sweep
   int reproducible;          // automatic choice restricted to bitwise reproducible kernels (hipeig_csr_set_reproducible)
   double absrow_max;         // max_i sum_j |a_ij| over the local rows: overflow bound of the fixed-point sweep (variant 5)
   // block-operand copies ("TCOO-B", spmm_device.h): one per interleave width, [0]: K = 4, [1]: K = 8; built on first use

@@ -6,6 +6,7 @@
 int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A);
 size_t hipeig_tcoo_lds_bytes(const hipeig_csr* A);
 size_t hipeig_tcoow_lds_bytes(const hipeig_csr* A);
+static int build_tcoow_layout(hipeig_ctx* c, hipeig_csr* A, int pair);
 
 // y[r] = a_self*xl[r] + a_sum*sum  (a_self = 0, a_sum = 1: plain product;
 // a_self = sign*sigma, a_sum = -sign: the shifted operator of numpyVector.py:152/154).
@@ -47,6 +48,40 @@ spmv_tcoow_kernel(TcooView T, const double* __restrict__ x, AxpyEpilogue epi) {
   __shared__ double red16[16];
   double acc = 0.0;
   tcoo_wg_sweep<AxpyEpilogue, FIXED>(T, x, epi, acc, tcoo_lds, red16);
+}
+
+// Complex operand, real operator, complex shift (the contour solves of feast.py:83-90 through GCROT): with
+// x = xr + i xi and z = zr + i zi,  y = sign*(z*x - H x):
+//   yr = sign*(zr*xr - H xr) - sign*zi*xi,   yi = sign*(zr*xi - H xi) + sign*zi*xr.
+// ar = sign*zr, ai = sign*zi, as = -sign (ar = ai = 0, as = 1: the plain product).  The real part of the
+// shift and the operator sum are rounded separately, like the reference's sigma*x - H@x.
+struct PairEpilogue {
+  double ar, ai, as;
+  const double* __restrict__ xr;
+  const double* __restrict__ xi;
+  double* __restrict__ yr;
+  double* __restrict__ yi;
+  __device__ __forceinline__ void row2(int64_t r, double sr, double si, double& acc) const {
+    const double vr = xr[r], vi = xi[r];
+    const double tr = add_rn(mul_rn(ar, vr), mul_rn(as, sr));
+    const double ti = add_rn(mul_rn(ar, vi), mul_rn(as, si));
+    yr[r] = fma(-ai, vi, tr);
+    yi[r] = fma(ai, vr, ti);
+  }
+};
+
+__global__ void __launch_bounds__(TCOOW_THREADS)
+spmv_tcoow_pair_kernel(TcooView T, const double* __restrict__ xpair, PairEpilogue epi) {
+  extern __shared__ double tcoo_lds[];
+  double acc = 0.0;
+  tcoo_wg_sweep<PairEpilogue, 0, 1>(T, xpair, epi, acc, tcoo_lds, nullptr);
+}
+
+// xp[i] = (xr[i], xi[i]): the interleaved operand of the pair sweep
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+pair_pack_kernel(int64_t n, const double* __restrict__ xr, const double* __restrict__ xi, double2* __restrict__ xp) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) xp[i] = make_double2(xr[i], xi[i]);
 }
 
 __global__ void __launch_bounds__(HIPEIG_BLOCK) absmax_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ partials) {
@@ -286,6 +321,74 @@ static int launch_spmv(hipeig_ctx* c, hipeig_csr* A, double a_self, double a_sum
   return 0;
 }
 
+// One sweep for both halves of a complex operand (see PairEpilogue).  Taken for operators the automatic choice
+// gives the TCOO-W kernel to (variant 4) on an unpartitioned context; everything else - small operators, pinned or
+// reproducible variants, row-partitioned runs - runs the two real sweeps and the two updates the pair replaces.
+static int launch_spmv_pair(hipeig_ctx* c, hipeig_csr* A, double zr, double zi, double sign,
+                            const double* xr, const double* xi, double* yr, double* yi) {
+  if (A->nrows == 0) return 0;
+  const double ar = sign * zr, ai = sign * zi, as = (sign == 0.0) ? 1.0 : -sign;
+  int variant = hipeig_csr_pick_variant(c, A);
+  if (variant < 0) return 1;
+  A->last_pair_fused = 0;
+  // Measured (tools/pair_bench.py, 64 non-zeros per row): N = 1e6 (32 per row) 0.227 -> 0.187 ms, 2e6 0.68 -> 0.50 ms,
+  // 4e6 1.38 -> 1.49 ms, 6e6 2.46 -> 2.45 ms, 8e6 3.29 -> 3.55 ms, 1e7 4.2 -> 4.7 ms (window / bin sizes change
+  // nothing): with two accumulators per row a unit holds half the rows, and once the rows no longer fit ONE launch
+  // the 16-byte gathers of the sparser tiles cost more line fills than the second pass over the stream saves.
+  const char* env = getenv("HIPEIG_PAIR_SWEEP");                     // 0 = always two sweeps, 1 = always the pair sweep
+  const bool one_launch = A->nrows <= (int64_t)c->num_cu * (TCOOW_MAX_RW / 2);
+  const bool want = variant == 4 && !c->collectives && (env ? atoi(env) != 0 : one_launch);
+  if (want) {
+    const int rc = build_tcoow_layout(c, A, 1);
+    if (rc == 1) return 1;
+    if (rc == 0 && !tcoow_ensure_parts(c, 2 * A->gather_len)) {
+      double* xp = c->ytmp;
+      hipLaunchKernelGGL(pair_pack_kernel, dim3(grid_for(A->gather_len, 2)), dim3(HIPEIG_BLOCK), 0, c->stream,
+                         A->gather_len, xr, xi, reinterpret_cast<double2*>(xp));
+      TcooView t = hipeig_tcoow_view(A);
+      t.idx = A->p_idx; t.val = A->p_val; t.off = A->p_off;
+      t.nunits = A->p_nunits; t.nwin = A->p_nwin; t.wbits = A->p_wbits; t.rw = A->p_rw;
+      t.win_lo = 0; t.win_hi = A->p_nwin;
+      PairEpilogue epi{ar, ai, as, xr + A->row_offset, xi + A->row_offset, yr, yi};
+      int g = A->p_wgs_per_sweep < A->p_nunits ? A->p_wgs_per_sweep : A->p_nunits;
+      const size_t lds = (size_t)2 * A->p_rw * sizeof(double) + ((size_t)A->p_nwin + 2) * sizeof(uint32_t);
+      for (int ub = 0; ub < A->p_nunits; ub += g) {                    // one launch per sweep
+        t.unit_begin = ub;
+        hipLaunchKernelGGL(spmv_tcoow_pair_kernel, dim3(g), dim3(TCOOW_THREADS), lds, c->stream, t, xp, epi);
+      }
+      HIPEIG_CHECK(hipGetLastError());
+      A->last_pair_fused = 1;
+      return 0;
+    }
+  }
+  const double a_self = (sign == 0.0) ? 0.0 : ar;
+  if (launch_spmv(c, A, a_self, as, xr, yr)) return 1;
+  if (launch_spmv(c, A, a_self, as, xi, yi)) return 1;
+  if (ai != 0.0) {
+    const int64_t o = c->collectives ? 0 : A->row_offset;
+    if (hipeig_axpby(c, A->nrows, -ai, xi + o, 1.0, yr)) return 1;
+    if (hipeig_axpby(c, A->nrows, ai, xr + o, 1.0, yi)) return 1;
+  }
+  return 0;
+}
+
+extern "C" int hipeig_spmv_shift_pair(hipeig_ctx* c, hipeig_csr* A, double zr, double zi, double sign,
+                                      const double* xr, const double* xi, double* yr, double* yi) {
+  HIPEIG_REQUIRE(xr != yr && xr != yi && xi != yr && xi != yi && yr != yi, "in-place product is not supported");
+  HIPEIG_REQUIRE(sign == 1.0 || sign == -1.0 || sign == 0.0, "sign must be +1, -1 or 0 (plain product)");
+  return launch_spmv_pair(c, A, zr, zi, sign, xr, xi, yr, yi);
+}
+
+extern "C" int hipeig_csr_pair_info(hipeig_csr* A, int64_t out[2]) {
+  out[0] = A->last_pair_fused;
+  out[1] = 0;
+  if (A->last_pair_fused && A->p_nunits > 0) {
+    const int g = A->p_wgs_per_sweep < A->p_nunits ? A->p_wgs_per_sweep : A->p_nunits;
+    out[1] = (A->p_nunits + g - 1) / g;
+  }
+  return 0;
+}
+
 extern "C" int hipeig_spmv(hipeig_ctx* c, hipeig_csr* A, const double* x, double* y) {
   HIPEIG_REQUIRE(x != y, "in-place product is not supported");
   return launch_spmv(c, A, 0.0, 1.0, x, y);
@@ -450,34 +553,37 @@ size_t hipeig_tcoow_lds_bytes(const hipeig_csr* A) {
   return (size_t)A->w_rw * sizeof(double) + ((size_t)A->w_nwin + 2) * sizeof(uint32_t);
 }
 
-int hipeig_csr_build_tcoow(hipeig_ctx* c, hipeig_csr* A) {
-  if (A->w_idx) return 0;
+// pair = 1 builds the copy of the pair sweep (two accumulators per row, so half the rows per unit; no column
+// splits) into the p_* fields; everything else is the same construction.
+static int build_tcoow_layout(hipeig_ctx* c, hipeig_csr* A, int pair) {
+  if (pair ? (A->p_idx != nullptr) : (A->w_idx != nullptr)) return 0;
   if (A->nnz == 0 || A->nrows == 0) return 2;
+  const int64_t max_rw = pair ? TCOOW_MAX_RW / 2 : TCOOW_MAX_RW;
   int wbits = 17;                                      // 15 bits are left for the row inside the unit
-  if (const char* e = getenv("HIPEIG_TCOOW_WBITS")) wbits = atoi(e);         // tuning knob
+  if (const char* e = getenv(pair ? "HIPEIG_TCOOW_PAIR_WBITS" : "HIPEIG_TCOOW_WBITS")) wbits = atoi(e);         // tuning knob
   HIPEIG_REQUIRE(wbits >= 10 && wbits <= 17, "HIPEIG_TCOOW_WBITS out of range");
   while (wbits > 10 && ((int64_t)1 << (wbits - 1)) >= A->gather_len) --wbits;
   const int nwin = (int)((A->gather_len + ((int64_t)1 << wbits) - 1) >> wbits);
   if (nwin > TCOOW_MAX_WIN) return 2;
   int binbits = 5;                                     // 32 columns = 2 lines of x per bin (measured: 4..6 equal)                                    // 2 Ki columns = 128 lines of x per bin
-  if (const char* e = getenv("HIPEIG_TCOOW_BINBITS")) binbits = atoi(e);     // tuning knob
+  if (const char* e = getenv(pair ? "HIPEIG_TCOOW_PAIR_BINBITS" : "HIPEIG_TCOOW_BINBITS")) binbits = atoi(e);     // tuning knob
   if (binbits > wbits) binbits = wbits;
-  HIPEIG_REQUIRE(binbits >= 4, "HIPEIG_TCOOW_BINBITS out of range");
+  HIPEIG_REQUIRE(binbits >= 3, "HIPEIG_TCOOW_BINBITS out of range");
   const int bpw = 1 << (wbits - binbits);
   const int64_t nbins = (int64_t)nwin * bpw;
   // one unit per CU if it fits; otherwise the fewest sweeps that fit the LDS, with the rows spread
   // evenly over sweeps * CUs units so that the last sweep is as full as the first
-  int64_t sweeps = (A->nrows + (int64_t)c->num_cu * TCOOW_MAX_RW - 1) / ((int64_t)c->num_cu * TCOOW_MAX_RW);
+  int64_t sweeps = (A->nrows + (int64_t)c->num_cu * max_rw - 1) / ((int64_t)c->num_cu * max_rw);
   if (sweeps < 1) sweeps = 1;
   int64_t rw = (A->nrows + sweeps * c->num_cu - 1) / (sweeps * c->num_cu);
   rw = (rw + 63) / 64 * 64;
   if (rw < 64) rw = 64;
-  if (rw > TCOOW_MAX_RW) rw = TCOOW_MAX_RW;
+  if (rw > max_rw) rw = max_rw;
   // Fewer full-size row blocks than half the CUs (a small operator, or the slab of a many-GPU run):
   // keep the row blocks as tall as the LDS allows and let `csplit` workgroups share each of them by
   // column ranges, so that the traffic of x through the L1s is (row blocks) x |x| instead of CUs x |x|.
   int csplit = 1;
-  {
+  if (!pair) {
     const int64_t rb_min = (A->nrows + TCOOW_MAX_RW - 1) / TCOOW_MAX_RW;
     // Worth it only when x is much larger than the L2s (measured: slab of N = 1e7 on 1/8 of the rows
     // 0.53 -> 0.34 ms, on 1/4 0.90 -> 0.62 ms; at N = 1e6, x = 8 MB, the combine launch costs more than
@@ -491,8 +597,8 @@ int hipeig_csr_build_tcoow(hipeig_ctx* c, hipeig_csr* A) {
       if (rw > TCOOW_MAX_RW) rw = TCOOW_MAX_RW;
     }
   }
-  if (const char* e = getenv("HIPEIG_TCOOW_RW")) rw = (atoi(e) + 63) / 64 * 64;   // tuning knob
-  HIPEIG_REQUIRE(rw >= 64 && rw <= TCOOW_MAX_RW && rw <= ((int64_t)1 << (32 - wbits)), "HIPEIG_TCOOW_RW out of range");
+  if (const char* e = getenv(pair ? "HIPEIG_TCOOW_PAIR_RW" : "HIPEIG_TCOOW_RW")) rw = (atoi(e) + 63) / 64 * 64;   // tuning knob
+  HIPEIG_REQUIRE(rw >= 64 && rw <= max_rw && rw <= ((int64_t)1 << (32 - wbits)), "HIPEIG_TCOOW_RW out of range");
   const int64_t nunits = (A->nrows + rw - 1) / rw;
   const size_t ncnt = (size_t)(nunits * nbins);
   HIPEIG_REQUIRE(ncnt < ((size_t)1 << 30), "too many (unit, bin) counters");
@@ -518,30 +624,41 @@ int hipeig_csr_build_tcoow(hipeig_ctx* c, hipeig_csr* A) {
   off[ntile] = (uint32_t)run;
   HIPEIG_REQUIRE(run == (uint64_t)A->nnz, "TCOO-W count pass lost non-zeros");
   HIPEIG_CHECK(hipMemcpyAsync(d_cur, cnt.data(), ncnt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  HIPEIG_CHECK(hipMalloc((void**)&A->w_off, (ntile + 1) * sizeof(uint32_t)));
+  uint32_t*& l_off = pair ? A->p_off : A->w_off;       // owned by the operator from the allocation on
+  uint32_t*& l_idx = pair ? A->p_idx : A->w_idx;
+  double*& l_val = pair ? A->p_val : A->w_val;
+  HIPEIG_CHECK(hipMalloc((void**)&l_off, (ntile + 1) * sizeof(uint32_t)));
   {
     // experiment knob: place the once-read stream in uncached (MTYPE_UC) memory so that it does not
     // occupy L2 lines / tag bandwidth next to the x window
     const char* uc = getenv("HIPEIG_TCOOW_UNCACHED");
     if (uc && atoi(uc) != 0) {
-      HIPEIG_CHECK(hipExtMallocWithFlags((void**)&A->w_idx, (size_t)A->nnz * sizeof(uint32_t), hipDeviceMallocUncached));
-      HIPEIG_CHECK(hipExtMallocWithFlags((void**)&A->w_val, (size_t)A->nnz * sizeof(double), hipDeviceMallocUncached));
+      HIPEIG_CHECK(hipExtMallocWithFlags((void**)&l_idx, (size_t)A->nnz * sizeof(uint32_t), hipDeviceMallocUncached));
+      HIPEIG_CHECK(hipExtMallocWithFlags((void**)&l_val, (size_t)A->nnz * sizeof(double), hipDeviceMallocUncached));
     } else {
-      HIPEIG_CHECK(hipMalloc((void**)&A->w_idx, (size_t)A->nnz * sizeof(uint32_t)));
-      HIPEIG_CHECK(hipMalloc((void**)&A->w_val, (size_t)A->nnz * sizeof(double)));
+      HIPEIG_CHECK(hipMalloc((void**)&l_idx, (size_t)A->nnz * sizeof(uint32_t)));
+      HIPEIG_CHECK(hipMalloc((void**)&l_val, (size_t)A->nnz * sizeof(double)));
     }
   }
-  HIPEIG_CHECK(hipMemcpyAsync(A->w_off, off.data(), (ntile + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIPEIG_CHECK(hipMemcpyAsync(l_off, off.data(), (ntile + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(tcoow_bin_kernel, dim3(grid), dim3(256), 0, c->stream, A->d_rowptr, A->d_col, A->d_val, A->nrows,
-                     (int)rw, binbits, (int)nbins, wbits, d_cur, A->w_idx, A->w_val, 1);
+                     (int)rw, binbits, (int)nbins, wbits, d_cur, l_idx, l_val, 1);
   HIPEIG_CHECK(hipGetLastError());
   HIPEIG_CHECK(hipStreamSynchronize(c->stream));
   HIPEIG_CHECK(hipFree(d_cur));
-  A->w_nunits = (int)nunits; A->w_nwin = nwin; A->w_wbits = wbits; A->w_rw = (int)rw;
-  A->w_csplit = csplit;
-  int per_cu = (int)(163840 / (rw * sizeof(double) + ((size_t)nwin + 2) * sizeof(uint32_t) + 256));
+  int per_cu = (int)(163840 / ((pair ? 2 : 1) * rw * sizeof(double) + ((size_t)nwin + 2) * sizeof(uint32_t) + 256));
   if (per_cu > 2) per_cu = 2;                          // 1024-thread workgroups: at most 32 waves per CU
   if (per_cu < 1) per_cu = 1;
+  if (pair) {
+    A->p_nunits = (int)nunits; A->p_nwin = nwin; A->p_wbits = wbits; A->p_rw = (int)rw;
+    A->p_wgs_per_sweep = per_cu * c->num_cu;
+    HIPEIG_CHECK(hipFuncSetAttribute((const void*)spmv_tcoow_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)HIPEIG_TCOOW_LDS_MAX));
+    A->bytes += (int64_t)A->nnz * 12 + (int64_t)(ntile + 1) * 4;
+    return 0;
+  }
+  A->w_nunits = (int)nunits; A->w_nwin = nwin; A->w_wbits = wbits; A->w_rw = (int)rw;
+  A->w_csplit = csplit;
   A->w_wgs_per_sweep = per_cu * c->num_cu;
   HIPEIG_CHECK(hipFuncSetAttribute((const void*)spmv_tcoow_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)HIPEIG_TCOOW_LDS_MAX));
@@ -562,6 +679,8 @@ int hipeig_csr_build_tcoow(hipeig_ctx* c, hipeig_csr* A) {
   A->bytes += (int64_t)A->nnz * 12 + (int64_t)(ntile + 1) * 4;
   return 0;
 }
+
+int hipeig_csr_build_tcoow(hipeig_ctx* c, hipeig_csr* A) { return build_tcoow_layout(c, A, 0); }
 
 // The variant a launch will use (building the TCOO copy on demand); -1 on failure.
 int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A) {
@@ -712,6 +831,9 @@ extern "C" int hipeig_csr_destroy(hipeig_ctx* c, hipeig_csr* A) {
   if (A->w_idx) hipFree(A->w_idx);
   if (A->w_val) hipFree(A->w_val);
   if (A->w_off) hipFree(A->w_off);
+  if (A->p_idx) hipFree(A->p_idx);
+  if (A->p_val) hipFree(A->p_val);
+  if (A->p_off) hipFree(A->p_off);
   for (int q = 0; q < 2; ++q) {
     if (A->bl[q].idx) hipFree(A->bl[q].idx);
     if (A->bl[q].val) hipFree(A->bl[q].val);

@@ -339,10 +339,15 @@ __device__ __forceinline__ void lds_add_i64_wg(double* slot, double scaled) {
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <class Epi, int FIXED = 0>
+// PAIR = 1: two operands at once (the real and imaginary halves of a complex vector, FEAST's contour solves):
+// x is the interleaved operand [column][2], a gather is ONE 16-byte read, every row has two accumulators
+// (yacc[2*row], yacc[2*row + 1]: T.rw <= TCOOW_MAX_RW / 2) and the epilogue is `row2(r, sum0, sum1, acc)`.
+// The (index, value) stream is read once for both products.  Plain sweeps only (no split / overlap / fixed point).
+template <class Epi, int FIXED = 0, int PAIR = 0>
 __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* __restrict__ x, const Epi& epi,
                                               double& acc, double* yacc /* rw doubles + (nwin+1) uint32 of LDS */,
                                               double* red16 = nullptr /* FIXED: 16 doubles of LDS */) {
+  static_assert(!(FIXED && PAIR), "the pair sweep has no fixed-point form");
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nw = blockDim.x >> 6;
   const uint32_t cmask = (1u << T.wbits) - 1u;
@@ -350,7 +355,7 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
   const int u = (T.csplit > 1) ? vb / T.csplit : vb;
   const int cs = (T.csplit > 1) ? vb - u * T.csplit : 0;
   if (u >= T.nunits) return;                         // uniform for the workgroup
-  uint32_t* offL = reinterpret_cast<uint32_t*>(yacc + T.rw);     // this unit's window offsets
+  uint32_t* offL = reinterpret_cast<uint32_t*>(yacc + (PAIR ? 2 : 1) * T.rw);     // this unit's window offsets
   const int64_t r0 = (int64_t)u * T.rw;
   double fx_scale = 1.0, fx_inv = 1.0;
   if (FIXED) {
@@ -360,10 +365,14 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
     fx_scale = fixed_point_scale(T.fx_bound, m);
     fx_inv = 1.0 / fx_scale;                         // exact: a power of two
   }
-  for (int k = threadIdx.x; k < T.rw; k += blockDim.x) {
-    const double y0 = (T.yinit && r0 + k < T.nrows) ? T.yinit[r0 + k] : 0.0;
-    if (FIXED) reinterpret_cast<long long*>(yacc)[k] = __double2ll_rn(y0 * fx_scale);
-    else yacc[k] = y0;
+  if (PAIR) {
+    for (int k = threadIdx.x; k < 2 * T.rw; k += blockDim.x) yacc[k] = 0.0;
+  } else {
+    for (int k = threadIdx.x; k < T.rw; k += blockDim.x) {
+      const double y0 = (T.yinit && r0 + k < T.nrows) ? T.yinit[r0 + k] : 0.0;
+      if (FIXED) reinterpret_cast<long long*>(yacc)[k] = __double2ll_rn(y0 * fx_scale);
+      else yacc[k] = y0;
+    }
   }
   for (int k = threadIdx.x; k <= T.nwin; k += blockDim.x) offL[k] = T.off[(size_t)u * T.nwin + k];
   __syncthreads();
@@ -405,14 +414,29 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
       while (q < send && c + 1 < T.nwin && q >= offL[c + 1]) ++c;                      \
       cw[j] = c;                                                                       \
     }                                                                                  \
+    double V2[TCOO_UNROLL];                                                            \
     if (!(TCOO_ABL(T, 1))) {                                                             \
       _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j)                          \
-        if (ID[j] != 0xFFFFFFFFu) V[j] *= tcoow_gather(x + (((size_t)((TCOO_ABL(T, 8)) ? 0 : cw[j]) << T.wbits) + (ID[j] & cmask))); \
+        if (ID[j] != 0xFFFFFFFFu) {                                                    \
+          const size_t gi = ((size_t)((TCOO_ABL(T, 8)) ? 0 : cw[j]) << T.wbits) + (ID[j] & cmask); \
+          if (PAIR) {                                                                  \
+            const double2 xv = *reinterpret_cast<const double2*>(x + 2 * gi);          \
+            V2[j] = V[j] * xv.y;                                                       \
+            V[j] *= xv.x;                                                              \
+          } else {                                                                     \
+            V[j] *= tcoow_gather(x + gi);                                              \
+          }                                                                            \
+        }                                                                              \
+    } else if (PAIR) {                                                                 \
+      _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j) V2[j] = V[j];            \
     }                                                                                  \
     if (!(TCOO_ABL(T, 2))) {                                                             \
       _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j)                          \
         if (ID[j] != 0xFFFFFFFFu) {                                                    \
-          if (FIXED) lds_add_i64_wg(yacc + (ID[j] >> T.wbits), V[j] * fx_scale);       \
+          if (PAIR) {                                                                  \
+            lds_add_f64_wg(yacc + 2 * (ID[j] >> T.wbits), V[j]);                       \
+            lds_add_f64_wg(yacc + 2 * (ID[j] >> T.wbits) + 1, V2[j]);                  \
+          } else if (FIXED) lds_add_i64_wg(yacc + (ID[j] >> T.wbits), V[j] * fx_scale); \
           else lds_add_f64_wg(yacc + (ID[j] >> T.wbits), V[j]);                        \
         }                                                                              \
     } else {                                                                           \
@@ -453,13 +477,18 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
 #undef TCOO_CONSUME
   asm volatile("" ::"v"(sink));
   __syncthreads();
-  if (T.raw_out) {
-    double* dst = T.raw_out + (int64_t)(T.part_base + cs) * T.part_stride;
+  if constexpr (PAIR) {
     for (int k = threadIdx.x; k < T.rw && r0 + k < T.nrows; k += blockDim.x)
-      dst[r0 + k] = FIXED ? (double)reinterpret_cast<const long long*>(yacc)[k] * fx_inv : yacc[k];
+      epi.row2(r0 + k, yacc[2 * k], yacc[2 * k + 1], acc);
   } else {
-    for (int k = threadIdx.x; k < T.rw && r0 + k < T.nrows; k += blockDim.x)
-      epi.row(r0 + k, FIXED ? (double)reinterpret_cast<const long long*>(yacc)[k] * fx_inv : yacc[k], acc);
+    if (T.raw_out) {
+      double* dst = T.raw_out + (int64_t)(T.part_base + cs) * T.part_stride;
+      for (int k = threadIdx.x; k < T.rw && r0 + k < T.nrows; k += blockDim.x)
+        dst[r0 + k] = FIXED ? (double)reinterpret_cast<const long long*>(yacc)[k] * fx_inv : yacc[k];
+    } else {
+      for (int k = threadIdx.x; k < T.rw && r0 + k < T.nrows; k += blockDim.x)
+        epi.row(r0 + k, FIXED ? (double)reinterpret_cast<const long long*>(yacc)[k] * fx_inv : yacc[k], acc);
+    }
   }
 }
 

@@ -288,6 +288,23 @@ class HipCsrOperator:
         _lib.call("hipeig_spmv_shift", self.ctx.handle, self.handle, float(sigma),
                   -1.0 if reverse else 1.0, x.ptr, y.ptr)
 
+    def apply_shifted_pair(self, z, xr, xi, yr, yi, reverse=False):
+        """(yr, yi) = sign*(z*x - H x) for the complex operand x = xr + i xi and the complex shift z (the operator is
+        real): one sweep of the operator for both halves on large operators (``hipeig_spmv_shift_pair``)."""
+        z = complex(z)
+        _lib.call("hipeig_spmv_shift_pair", self.ctx.handle, self.handle, z.real, z.imag,
+                  -1.0 if reverse else 1.0, xr.ptr, xi.ptr, yr.ptr, yi.ptr)
+
+    def apply_pair(self, xr, xi, yr, yi):
+        """(yr, yi) = (H xr, H xi): ``applyOp`` on a complex vector, one sweep where the pair kernel applies."""
+        _lib.call("hipeig_spmv_shift_pair", self.ctx.handle, self.handle, 0.0, 0.0, 0.0, xr.ptr, xi.ptr, yr.ptr, yi.ptr)
+
+    def pair_info(self):
+        """{'fused': the most recent pair product ran as one sweep, 'launches': its sweep launches}"""
+        out = (C.c_int64 * 2)()
+        _lib.call("hipeig_csr_pair_info", self.handle, out)
+        return {"fused": bool(out[0]), "launches": int(out[1])}
+
     def __matmul__(self, v):
         if isinstance(v, HipVector):
             return v.applyOp(self)
@@ -626,10 +643,7 @@ class HipVector(AbstractVector):
 
         def matvec(v):                                  # sgn * ((zr + i zi)(vr + i vi) - H vr - i H vi)
             out_r, out_i = ctx.alloc(n), ctx.alloc(n)
-            H.apply_shifted(z.real, v[0], out_r, reverse=reverseGF)         # sgn*(zr vr - H vr)
-            H.apply_shifted(z.real, v[1], out_i, reverse=reverseGF)         # sgn*(zr vi - H vi)
-            _lib.call("hipeig_axpby", ctx.handle, n, -sgn * z.imag, v[1].ptr, 1.0, out_r.ptr)
-            _lib.call("hipeig_axpby", ctx.handle, n, sgn * z.imag, v[0].ptr, 1.0, out_i.ptr)
+            H.apply_shifted_pair(z, v[0], v[1], out_r, out_i, reverse=reverseGF)
             return (out_r, out_i)
 
         if isinstance(b, HipComplexVector):
@@ -818,7 +832,11 @@ class HipComplexVector(AbstractVector):
         return HipComplexVector(self.re.copy(), self.im.copy())
 
     def applyOp(self, other):
-        return HipComplexVector(self.re.applyOp(other), self.im.applyOp(other))
+        if not isinstance(other, HipCsrOperator):
+            raise TypeError("HipComplexVector.applyOp needs a HipCsrOperator (device-resident CSR)")
+        out_r, out_i = self.re.ctx.alloc(other.nrows), self.re.ctx.alloc(other.nrows)
+        other.apply_pair(self.re._buf, self.im._buf, out_r, out_i)
+        return HipComplexVector(self.re._new(out_r), self.im._new(out_i))
 
     def compress(self):
         return self

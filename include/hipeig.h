@@ -178,6 +178,14 @@ int hipeig_spmv(hipeig_ctx* ctx, hipeig_csr* A, const double* x, double* y);
  * y = sign*(sigma*x - H x), sign = +1 (Green's function) or -1 (reverseGF)               */
 int hipeig_spmv_shift(hipeig_ctx* ctx, hipeig_csr* A, double sigma, double sign,
                       const double* x, double* y);
+/* The same lambda for a COMPLEX shift and operand (feast.py:83-90 -> numpyVector.py:152-161 with sigma = z_k on the
+ * contour; H real): y = sign*(z*x - H x) with x = xr + i xi, z = zr + i zi, y = yr + i yi, the halves in separate
+ * buffers.  sign = 0: the plain product y = H x (applyOp on a complex vector, numpyVector.py:98-100).  On a large
+ * unpartitioned operator both halves share ONE sweep of the (index, value) stream; otherwise two sweeps.
+ * hipeig_csr_pair_info: out[0] = 1 when the most recent call took the one-sweep form, out[1] = its launches.       */
+int hipeig_spmv_shift_pair(hipeig_ctx* ctx, hipeig_csr* A, double zr, double zi, double sign,
+                           const double* xr, const double* xi, double* yr, double* yi);
+int hipeig_csr_pair_info(hipeig_csr* A, int64_t out[2]);
 
 /* The k applications of matrixRepresentation (numpyVector.py:184-185) as ONE block product:
  * Y[j] = H X[j], j < k.  Internally the operands are interleaved so that each non-zero costs

@@ -224,3 +224,117 @@ def test_complex_vectors_match_the_ndarray_backend(hip, gapped4000):
     assert np.linalg.norm(wz.array - exact_z) <= 1e-7 * np.linalg.norm(exact_z)
     wz_ref = RefVector.solve(Hh, RefVector(b.copy(), og), z)
     assert np.linalg.norm(wz.array - wz_ref.array) <= 1e-7 * np.linalg.norm(exact_z)
+
+
+# ---------------------------------------------------------------- one sweep for both halves of a complex operand
+def _ragged_csr(rng, n, ncols, dense_row=None):
+    rows = []
+    for i in range(n):
+        if i % 7 == 0:
+            k = 0                                           # empty rows
+        elif i == 11:
+            k = 2600
+        elif dense_row is not None and i == dense_row:
+            k = 5000
+        else:
+            k = int(rng.integers(1, 40))
+        rows.append((rng.integers(0, ncols, size=k), rng.standard_normal(k)))     # unsorted, duplicates allowed
+    rowptr = np.concatenate([[0], np.cumsum([len(c) for c, _ in rows])]).astype(np.int64)
+    col = np.concatenate([c for c, _ in rows]).astype(np.int32)
+    val = np.concatenate([v for _, v in rows])
+    return rowptr, col, val
+
+
+def test_pair_product_one_sweep_for_a_complex_operand(hip, monkeypatch):
+    """``hipeig_spmv_shift_pair``: y = sign*(z x - H x) for complex x, z and the real operator (the GCROT matvec of
+    the contour solves, feast.py:83-90 -> numpyVector.py:152-161).  On operators that take the column-window
+    blocked kernel both halves share one sweep of the index / value stream (interleaved operand, two accumulators
+    per row); the result must agree with the complex product on the host to 2e-14 of the row's absolute sum - for
+    ragged rows (empty, longer than a batch, duplicates, unsorted), several column windows and several row units,
+    a rectangular slab applied to a full-length operand, both signs and the plain product.  Small or pinned
+    operators keep the two-sweep form with the same result."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(31)
+    n = 300_000                                             # 3 column windows of 2^17; units of <= 10112 rows
+    rowptr, col, val = _ragged_csr(rng, n, n, dense_row=150_001)
+    A = sp.csr_matrix((val.copy(), col.copy(), rowptr.copy()), shape=(n, n))
+    Aabs = sp.csr_matrix((np.abs(val), col.copy(), rowptr.copy()), shape=(n, n))
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    ref = A @ x
+    scale = Aabs @ np.abs(x) + np.abs(x) + 1e-300
+    H = hip.HipCsrOperator.from_csr_arrays(rowptr, col, val, n)
+    H.set_variant(4)
+    ctx = hip.HipContext.default()
+    xr, xi = hip.HipVector(x.real.copy()), hip.HipVector(x.imag.copy())
+    yr, yi = ctx.alloc(n), ctx.alloc(n)
+
+    def result():
+        return hip.HipVector(yr).array + 1j * hip.HipVector(yi).array
+
+    z = 0.37 - 1.9j
+    for reverse, sgn in ((False, 1.0), (True, -1.0)):
+        H.apply_shifted_pair(z, xr._buf, xi._buf, yr, yi, reverse=reverse)
+        assert H.pair_info()["fused"] and H.pair_info()["launches"] >= 1
+        _w = result()
+        assert np.all(np.abs(_w - sgn * (z * x - ref)) <= 2e-14 * abs(z) * scale)
+    H.apply_pair(xr._buf, xi._buf, yr, yi)
+    got = result()
+    assert np.all(np.abs(got - ref) <= 2e-14 * scale)
+    assert np.all(got[::7] == 0.0)                          # empty rows
+    # the two-sweep form (what a small / pinned / partitioned operator runs) gives the same numbers to rounding
+    monkeypatch.setenv("HIPEIG_PAIR_SWEEP", "0")
+    H.apply_shifted_pair(z, xr._buf, xi._buf, yr, yi)
+    assert not H.pair_info()["fused"]
+    assert np.all(np.abs(result() - (z * x - ref)) <= 2e-14 * abs(z) * scale)
+    monkeypatch.delenv("HIPEIG_PAIR_SWEEP")
+    # complex device vectors reach it through applyOp
+    ay = hip.HipVector(x.copy()).applyOp(H)
+    assert type(ay) is hip.HipComplexVector and H.pair_info()["fused"]
+    assert np.all(np.abs(ay.array - ref) <= 2e-14 * scale)
+    # rectangular slab (rows 1000..250000) applied to a full-length operand
+    slab = hip.HipCsrOperator.from_scipy(A, 1000, 250_000)
+    slab.set_variant(4)
+    sr, si = ctx.alloc(249_000), ctx.alloc(249_000)
+    slab.apply_shifted_pair(z, xr._buf, xi._buf, sr, si)
+    assert slab.pair_info()["fused"]
+    gs = hip.HipVector(sr).array + 1j * hip.HipVector(si).array
+    assert np.all(np.abs(gs - (z * x - ref)[1000:250_000]) <= 2e-14 * abs(z) * scale[1000:250_000])
+    # a small operator streams (CSR kernel): two sweeps, same contract
+    m = 3000
+    rp2, c2, v2 = _ragged_csr(rng, m, m)
+    B = sp.csr_matrix((v2.copy(), c2.copy(), rp2.copy()), shape=(m, m))
+    Hs = hip.HipCsrOperator.from_csr_arrays(rp2, c2, v2, m)
+    xs = rng.standard_normal(m) + 1j * rng.standard_normal(m)
+    ur, ui = ctx.alloc(m), ctx.alloc(m)
+    Hs.apply_shifted_pair(z, hip.HipVector(xs.real.copy())._buf, hip.HipVector(xs.imag.copy())._buf, ur, ui)
+    assert not Hs.pair_info()["fused"]
+    sc2 = sp.csr_matrix((np.abs(v2), c2.copy(), rp2.copy()), shape=(m, m)) @ np.abs(xs) + np.abs(xs)
+    assert np.all(np.abs(hip.HipVector(ur).array + 1j * hip.HipVector(ui).array - (z * xs - B @ xs)) <= 2e-14 * abs(z) * sc2)
+    with pytest.raises(Exception):
+        H.apply_shifted_pair(z, xr._buf, xi._buf, xr._buf, yi)          # in place
+
+
+def test_pair_product_at_the_size_of_the_baseline_operator(hip):
+    """The pair sweep on the N = 1e6 operator of BASELINE configs #2/#3/#5 (generated on the device): equal to the
+    two real products to rounding, linear, and consistent with the symmetric operator (<u, H w> = <H u, w>)."""
+    N = 1_000_000
+    H = hip.HipCsrOperator.generate(N, 32, seed=7)
+    ctx = hip.HipContext.default()
+    rng = np.random.default_rng(3)
+    u, w = rng.standard_normal(N), rng.standard_normal(N)
+    U, W = hip.HipVector(u), hip.HipVector(w)
+    Z = hip.HipVector(u + 1j * w)
+    HZ = Z.applyOp(H)
+    assert H.pair_info()["fused"]
+    HU, HW = U.applyOp(H), W.applyOp(H)
+    bound = 1e-13 * max(HU.norm(), HW.norm())
+    assert hip.HipVector.linearCombination([HZ.re, HU], [1.0, -1.0]).norm() <= bound
+    assert hip.HipVector.linearCombination([HZ.im, HW], [1.0, -1.0]).norm() <= bound
+    assert abs(U.vdot(HZ.im) - W.vdot(HZ.re)) <= 1e-12 * U.norm() * HW.norm()          # symmetry of H
+    z = 0.02 + 0.11j
+    yr, yi = ctx.alloc(N), ctx.alloc(N)
+    H.apply_shifted_pair(z, U._buf, W._buf, yr, yi)
+    want_r = hip.HipVector.linearCombination([U, W, HU], [z.real, -z.imag, -1.0])
+    want_i = hip.HipVector.linearCombination([W, U, HW], [z.real, z.imag, -1.0])
+    assert hip.HipVector.linearCombination([hip.HipVector(yr), want_r], [1.0, -1.0]).norm() <= 1e-13 * want_r.norm()
+    assert hip.HipVector.linearCombination([hip.HipVector(yi), want_i], [1.0, -1.0]).norm() <= 1e-13 * want_i.norm()
