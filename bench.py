@@ -116,6 +116,18 @@ def main(result):
     singles.sort()
     step_median, step_min = allmax(singles[len(singles) // 2]), allmax(singles[0])
 
+    # what a plain streaming kernel reaches on THIS device (confirm the nominal figure on the
+    # box): out-of-place scale of 1e8 doubles, 0.8 GB read + 0.8 GB written per call, well past the Infinity Cache
+    ncopy = 100_000_000
+    ca, cb = ctx.alloc(ncopy), ctx.alloc(ncopy)
+    ea._lib.call("hipeig_vec_fill", ctx.handle, ca.ptr, ncopy, 1.0)
+    ea._lib.call("hipeig_scale", ctx.handle, ncopy, 1.0000001, ca.ptr, cb.ptr)
+    ctx.timer_start()
+    for _ in range(10):
+        ea._lib.call("hipeig_scale", ctx.handle, ncopy, 1.0000001, ca.ptr, cb.ptr)
+    copy_gbs = -allmax(-(16.0 * ncopy / 1e9) / (ctx.timer_stop() / 10 / 1e3))     # the slowest rank's rate
+    del ca, cb
+
     gbytes = global_bytes(N, nnz_total) / 1e9
     value = gbytes * a.steps / wall
     per_gpu_bytes = H.algorithmic_bytes() / 1e9          # local rows, x counted once (full length)
@@ -146,6 +158,7 @@ def main(result):
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4), "achievable_peak": HBM_ACHIEVABLE_GBS,
+                     "measured_stream_GBs": round(copy_gbs, 1), "frac_of_measured_stream": round(achieved / copy_gbs, 4),
                      "traffic": traffic,
                      "traffic_source": "profiles/pmc_current.json (separate rocprofv3 --pmc passes)" if traffic else None,
                      "launches_per_step": nlaunch,

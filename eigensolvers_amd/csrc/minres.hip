@@ -2,10 +2,16 @@
 // linearSolver="minres", numpyVector.py:147-178; the recurrences are SciPy 1.15.3's
 // scipy.sparse.linalg.minres, the third-party routine the reference calls at :163).
 //
-// One iteration = three kernels, no host round trip:
+// One iteration = three steps, no host round trip:
 //   KA  y = A v - (beta/oldb) r1,  v = r2/beta        (CSR sweep, fused)   + partial <v,y>
 //   KC  y -= (alfa/beta) r2                                              + partial <y,y>
 //   KD  w = (v - oldeps*w1 - delta*w2)/gamma ; x += phi*w                 + partial <x,x>
+// and two kernels on a single GPU: KD(k) is element-wise and needs nothing but beta_{k+1} = sqrt(<y,y>), which KA(k+1)
+// needs as well, so it runs in the row epilogue of KA(k+1)'s sweep (r1 of that sweep IS the r2 that KD(k) reads);
+// the stopping tests of iteration k then sit in KC(k+1)'s prologue, where <x,x> has arrived.  Two global
+// reductions per iteration (alfa, beta) is the least SciPy's recurrences allow.  A chunk of iterations ends with a
+// stand-alone KD + the check kernel, and the next chunk's first KA has nothing pending.  HIPEIG_MINRES_FUSE_KD=0
+// keeps the three-kernel form.
 // The recurrence scalars live in a ring of three MinresState records in device memory: each
 // kernel reads one record and workgroup 0 writes the next, every workgroup having first
 // reduced the previous kernel's <= 2048 partial sums in its prologue (fixed order, so all
@@ -29,6 +35,16 @@ size_t hipeig_tcoo_lds_bytes(const hipeig_csr* A);
 
 #include "minres_device.h"
 
+// KD's element: w = (v - oldeps*w1 - delta*w2)*denom ; x += phi*w with v = s_old*r2old.  One definition for the
+// stand-alone kernel and for the epilogue form, so that both evaluate the same expression.
+struct MinresKd {
+  double s_old, oldeps, delta, denom, phi;
+  __device__ __forceinline__ void apply(double r2old, double a1, double a2, double& wn, double& xv) const {
+    wn = (s_old * r2old - oldeps * a1 - delta * a2) * denom;
+    xv += phi * wn;
+  }
+};
+
 struct MinresRowEpilogue {
   double sigma, sign, s, c1;
   int use_r1;
@@ -36,14 +52,39 @@ struct MinresRowEpilogue {
   const double* __restrict__ r1;
   double* __restrict__ y;
   double* yy;                       // fused (distributed) form: running <y,y> of this thread, else null
+  // KD of the previous iteration riding on this sweep (single GPU): r1 is the r2 it reads
+  int do_kd;
+  MinresKd kd;
+  const double* __restrict__ w1;
+  const double* __restrict__ w2;
+  double* __restrict__ w;
+  double* __restrict__ x;
+  double* xx;                       // running <x,x> of this thread
   __device__ __forceinline__ void row(int64_t r, double sum, double& acc) const {
     const double v = s * r2l[r];
     double yv = sign * (mul_rn(sigma, v) - s * sum);
-    if (use_r1) yv -= c1 * r1[r];
+    const double r1v = (use_r1 || do_kd) ? r1[r] : 0.0;
+    if (use_r1) yv -= c1 * r1v;
     y[r] = yv;
     acc = fma(v, yv, acc);
     if (yy) *yy = fma(yv, yv, *yy);
+    if (do_kd) {
+      double wn, xv = x[r];
+      kd.apply(r1v, w1[r], w2[r], wn, xv);
+      w[r] = wn; x[r] = xv;
+      *xx = fma(xv, xv, *xx);
+    }
   }
+};
+
+// What the KD riding on a KA launch needs besides the state record.
+struct MinresKdArgs {
+  int do_kd;
+  const double* w1;
+  const double* w2;
+  double* w;
+  double* x;
+  double* partials;                 // <x,x> partials, laid out like the launch's <v,y> partials
 };
 
 // VARIANT 1-4: the operator sweep of that layout.  VARIANT 5: the combine step of a split TCOO-W sweep
@@ -59,24 +100,39 @@ template <int VARIANT, int FUSED = 0, int FIXED = 0>
 __global__ void __launch_bounds__(VARIANT == 4 ? TCOOW_THREADS : HIPEIG_BLOCK)
 minres_ka_kernel(CsrView A, TcooView T, const double* __restrict__ xg, MinresArgs a, const MinresState* __restrict__ Sin,
                  MinresState* __restrict__ Sout, const double* __restrict__ r2l,
-                 const double* __restrict__ r1, double* __restrict__ y, double* __restrict__ partials) {
+                 const double* __restrict__ r1, double* __restrict__ y, double* __restrict__ partials,
+                 MinresKdArgs kda = MinresKdArgs{0, nullptr, nullptr, nullptr, nullptr, nullptr}) {
   __shared__ double prod[VARIANT == 2 ? SPMV_NNZ_PER_BLOCK : 8];
   __shared__ double red[16];
   extern __shared__ double tcoo_lds[];
   MinresState S = *Sin;
+  MinresRowEpilogue epi;
+  epi.do_kd = 0;
   if (!FUSED) {
-    const double xx = (S.itn > 0 && !S.done) ? sum_or_value(a.pD, a.nD, red) : 0.0;
-    minres_tests(S, xx, a);
+    if (kda.do_kd) {
+      // Sin is the record KC left: the scalar half of KD (minres_kd_kernel) happens here, its vector half in the
+      // epilogue; the tests of that iteration wait for its <x,x> (KC's prologue)
+      if (!S.done) {
+        const double bb = sum_or_value(a.pC, a.nC, red);
+        epi.kd.s_old = S.s;
+        minres_advance(S, bb);
+        epi.kd.oldeps = S.oldeps; epi.kd.delta = S.delta; epi.kd.denom = S.denom; epi.kd.phi = S.phi;
+        epi.do_kd = 1;
+      }
+    } else {
+      const double xx = (S.itn > 0 && !S.done) ? sum_or_value(a.pD, a.nD, red) : 0.0;
+      minres_tests(S, xx, a);
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
   if (S.done) return;
-  MinresRowEpilogue epi;
   epi.sigma = a.sigma; epi.sign = a.sign; epi.s = S.s;
   epi.use_r1 = S.itn >= 1;
   epi.c1 = epi.use_r1 ? S.beta / S.oldb : 0.0;
   epi.r2l = r2l; epi.r1 = r1; epi.y = y;
-  double acc = 0.0, acc_yy = 0.0;
+  double acc = 0.0, acc_yy = 0.0, acc_xx = 0.0;
   epi.yy = FUSED ? &acc_yy : nullptr;
+  epi.w1 = kda.w1; epi.w2 = kda.w2; epi.w = kda.w; epi.x = kda.x; epi.xx = &acc_xx;
   if (VARIANT == 5) tcoow_combine_sweep(T.raw_out, T.part_base, T.part_stride, T.nrows, epi, acc);
   else if (VARIANT == 4) tcoo_wg_sweep<MinresRowEpilogue, FIXED>(T, xg, epi, acc, tcoo_lds, red);
   else if (VARIANT == 3) tcoo_sweep(T, xg, epi, acc, tcoo_lds);
@@ -88,6 +144,10 @@ minres_ka_kernel(CsrView A, TcooView T, const double* __restrict__ xg, MinresArg
   if (FUSED) {
     acc_yy = block_reduce_sum(acc_yy, red);
     if (threadIdx.x == 0) partials[HIPEIG_MAX_PARTIALS + blockIdx.x] = acc_yy;
+  }
+  if (!FUSED && kda.do_kd) {                                 // uniform: every workgroup saw the same record
+    acc_xx = block_reduce_sum(acc_xx, red);
+    if (threadIdx.x == 0) kda.partials[blockIdx.x] = acc_xx;
   }
 }
 
@@ -149,9 +209,15 @@ minres_kcd_fused_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__
 
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
 minres_kc_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, MinresState* __restrict__ Sout,
-                 const double* __restrict__ r2, double* __restrict__ y, double* __restrict__ partials) {
+                 const double* __restrict__ r2, double* __restrict__ y, double* __restrict__ partials, int test_prev = 0) {
   __shared__ double red[4];
   MinresState S = *Sin;
+  if (test_prev && !S.done) {
+    // the previous iteration's KD ran in the epilogue of the sweep before this kernel: its stopping tests, with
+    // the <x,x> that sweep has left
+    const double xx = S.itn > 0 ? sum_or_value(a.pD, a.nD, red) : 0.0;
+    minres_tests(S, xx, a);
+  }
   if (S.done) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
     return;
@@ -195,7 +261,7 @@ minres_kd_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, M
   minres_advance(S, bb);      // scalar recurrences (every thread, identical)
   if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
   // ---- w = (v - oldeps*w1 - delta*w2)*denom ; x += phi*w ----
-  const double oldeps = S.oldeps, delta = S.delta, denom = S.denom, phi = S.phi;
+  const MinresKd kd{s_old, S.oldeps, S.delta, S.denom, S.phi};
   const int64_t n2 = n >> 1;
   const double2* r2 = reinterpret_cast<const double2*>(r2old);
   const double2* w12 = reinterpret_cast<const double2*>(w1);
@@ -207,17 +273,16 @@ minres_kd_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, M
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
     const double2 rv = r2[i], a1 = w12[i], a2 = w22[i];
     double2 xv = x2[i], wn;
-    wn.x = (s_old * rv.x - oldeps * a1.x - delta * a2.x) * denom;
-    wn.y = (s_old * rv.y - oldeps * a1.y - delta * a2.y) * denom;
-    xv.x += phi * wn.x; xv.y += phi * wn.y;
+    kd.apply(rv.x, a1.x, a2.x, wn.x, xv.x);
+    kd.apply(rv.y, a1.y, a2.y, wn.y, xv.y);
     wn2[i] = wn;
     x2[i] = xv;
     acc = fma(xv.x, xv.x, acc); acc = fma(xv.y, xv.y, acc);
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
-    const double wn = (s_old * r2old[i] - oldeps * w1[i] - delta * w2[i]) * denom;
-    const double xv = x[i] + phi * wn;
+    double wn, xv = x[i];
+    kd.apply(r2old[i], w1[i], w2[i], wn, xv);
     w[i] = wn; x[i] = xv;
     acc = fma(xv, xv, acc);
   }
@@ -333,14 +398,23 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
   if (dist) HIPEIG_CHECK(hipMemsetAsync(pA, 0, (size_t)4 * HIPEIG_MAX_PARTIALS * sizeof(double), c->stream));
   c->mr_collectives = 0;
 
-  // The operator sweep of iteration k (all variants); FUSED: also leaves the <y,y> partials.
-  auto enqueue_ka = [&](int fused, double* r2, double* r1, double* yb) -> int {
+  // Single GPU: KD(k) rides on the sweep of KA(k+1) (two kernels per iteration, see the header).
+  const char* fk_env = getenv("HIPEIG_MINRES_FUSE_KD");
+  const bool fuse_kd = !dist && !(fk_env && atoi(fk_env) == 0);
+  MinresArgs a_kc = a;                                       // KC after such a sweep: <x,x> partials laid out like <v,y>
+  a_kc.nD = nPA;
+
+  // The operator sweep of iteration k (all variants); FUSED: also leaves the <y,y> partials.  `kd`: the pending KD of
+  // the previous iteration (do_kd = 0: none), `Sin`: the record the sweep starts from.
+  auto enqueue_ka = [&](int fused, double* r2, double* r1, double* yb, const MinresState* Sin, MinresKdArgs kd) -> int {
     const double* xg = nullptr;
     TcooView tv = tview;
-#define KA_LAUNCH(VAR, GRID, THREADS, LDS, TV, PARTS)                                                               \
+#define KA_LAUNCH(VAR, GRID, THREADS, LDS, TV, PARTS, KDP)                                                          \
     do {                                                                                                            \
-      if (fused) hipLaunchKernelGGL((minres_ka_kernel<VAR, 1>), dim3(GRID), dim3(THREADS), LDS, c->stream, view, TV, xg, a, V + 0, V + 1, r2, r1, yb, PARTS); \
-      else hipLaunchKernelGGL((minres_ka_kernel<VAR, 0>), dim3(GRID), dim3(THREADS), LDS, c->stream, view, TV, xg, a, V + 0, V + 1, r2, r1, yb, PARTS);      \
+      MinresKdArgs kl = kd;                                                                                         \
+      kl.partials = KDP;                                                                                            \
+      if (fused) hipLaunchKernelGGL((minres_ka_kernel<VAR, 1>), dim3(GRID), dim3(THREADS), LDS, c->stream, view, TV, xg, a, Sin, V + 1, r2, r1, yb, PARTS, kl); \
+      else hipLaunchKernelGGL((minres_ka_kernel<VAR, 0>), dim3(GRID), dim3(THREADS), LDS, c->stream, view, TV, xg, a, Sin, V + 1, r2, r1, yb, PARTS, kl);      \
     } while (0)
     if (variant == 4) {
       int ncombine = 0;                                           // local windows under the all-gather
@@ -350,16 +424,18 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
       for (int sw = 0; sw < nsweepA; ++sw) {
         tv.unit_begin = sw * gA;
         if (fixed) {
-          if (fused) hipLaunchKernelGGL((minres_ka_kernel<4, 1, 1>), dim3(gA), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, view, tv, xg, a, V + 0, V + 1, r2, r1, yb, pA + sw * gA);
-          else hipLaunchKernelGGL((minres_ka_kernel<4, 0, 1>), dim3(gA), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, view, tv, xg, a, V + 0, V + 1, r2, r1, yb, pA + sw * gA);
+          MinresKdArgs kl = kd;
+          kl.partials = pD + sw * gA;
+          if (fused) hipLaunchKernelGGL((minres_ka_kernel<4, 1, 1>), dim3(gA), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, view, tv, xg, a, Sin, V + 1, r2, r1, yb, pA + sw * gA, kl);
+          else hipLaunchKernelGGL((minres_ka_kernel<4, 0, 1>), dim3(gA), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, view, tv, xg, a, Sin, V + 1, r2, r1, yb, pA + sw * gA, kl);
         } else {
-          KA_LAUNCH(4, gA, TCOOW_THREADS, hipeig_tcoow_lds_bytes(A), tv, pA + sw * gA);
+          KA_LAUNCH(4, gA, TCOOW_THREADS, hipeig_tcoow_lds_bytes(A), tv, pA + sw * gA, pD + sw * gA);
         }
       }
       if (ncombine) {
         TcooView tc = tv;
         tc.part_base = ncombine;                                  // number of slabs to add
-        KA_LAUNCH(5, gE, HIPEIG_BLOCK, 0, tc, pA);
+        KA_LAUNCH(5, gE, HIPEIG_BLOCK, 0, tc, pA, pD);
       }
       return 0;
     }
@@ -368,19 +444,21 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
     if (variant == 3) {
       for (int sw = 0; sw < nsweepA; ++sw) {       // one launch per sweep; partials side by side
         tv.unit_begin = sw * gA * 4;
-        KA_LAUNCH(3, gA, HIPEIG_BLOCK, hipeig_tcoo_lds_bytes(A), tv, pA + sw * gA);
+        KA_LAUNCH(3, gA, HIPEIG_BLOCK, hipeig_tcoo_lds_bytes(A), tv, pA + sw * gA, pD + sw * gA);
       }
     } else if (variant == 1) {
-      KA_LAUNCH(1, gA, HIPEIG_BLOCK, 0, tview, pA);
+      KA_LAUNCH(1, gA, HIPEIG_BLOCK, 0, tview, pA, pD);
     } else {
-      KA_LAUNCH(2, gA, HIPEIG_BLOCK, 0, tview, pA);
+      KA_LAUNCH(2, gA, HIPEIG_BLOCK, 0, tview, pA, pD);
     }
 #undef KA_LAUNCH
     return 0;
   };
 
-  // One iteration's launches on the compute stream (buffer roles rotate with period 3).
-  auto enqueue_iteration = [&](int k) -> int {
+  const MinresKdArgs no_kd{0, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // One iteration's launches on the compute stream (buffer roles rotate with period 3).  `first`: nothing is pending
+  // from the iteration before (the first iteration of a chunk: the chunk before ended with a stand-alone KD).
+  auto enqueue_iteration = [&](int k, bool first) -> int {
     double* r2 = R[k % 3];
     double* yb = R[(k + 1) % 3];
     double* r1 = R[(k + 2) % 3];
@@ -389,15 +467,29 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
     double* w2 = W[(k + 2) % 3];
     if (dist) {
       // all-gather + sweep, ONE all-reduce, fused update: 2 collectives and 2 (+ sweeps) launches
-      if (enqueue_ka(1, r2, r1, yb)) return 4;
+      if (enqueue_ka(1, r2, r1, yb, V + 0, no_kd)) return 4;
       if (hipeig_allreduce_sum(c, pA, 3 * HIPEIG_MAX_PARTIALS)) return 4;
       ++c->mr_collectives;
       hipLaunchKernelGGL(minres_kcd_fused_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 1, V + 0, r2, yb, w1, w2, wn, xw, pD);
       return 0;
     }
-    if (enqueue_ka(0, r2, r1, yb)) return 4;
-    hipLaunchKernelGGL(minres_kc_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 1, V + 2, r2, yb, pC);
+    if (fuse_kd) {
+      // KD(k-1): w = W[(k-1)%3] from w1 = W[k%3], w2 = W[(k+1)%3] and r2 of that iteration = this one's r1
+      const bool pending = !first;
+      const MinresKdArgs kd{pending ? 1 : 0, wn, w1, w2, xw, nullptr};
+      if (enqueue_ka(0, r2, r1, yb, pending ? V + 2 : V + 0, kd)) return 4;
+      hipLaunchKernelGGL(minres_kc_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, pending ? a_kc : a, V + 1, V + 2, r2, yb, pC, pending ? 1 : 0);
+      return 0;
+    }
+    if (enqueue_ka(0, r2, r1, yb, V + 0, no_kd)) return 4;
+    hipLaunchKernelGGL(minres_kc_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 1, V + 2, r2, yb, pC, 0);
     hipLaunchKernelGGL(minres_kd_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 2, V + 0, r2, w1, w2, wn, xw, pD);
+    return 0;
+  };
+  // The KD of a chunk's last iteration k (nothing follows it inside the chunk to ride on).
+  auto enqueue_last_kd = [&](int k) -> int {
+    if (!fuse_kd) return 0;
+    hipLaunchKernelGGL(minres_kd_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 2, V + 0, R[k % 3], W[(k + 1) % 3], W[(k + 2) % 3], W[k % 3], xw, pD);
     return 0;
   };
   // diagnostic knobs for the rocprofv3-inside-capture question (profiles/r02_hipgraph_under_rocprofv3.txt):
@@ -444,6 +536,7 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
     key.lds = (variant == 4) ? (int64_t)hipeig_tcoow_lds_bytes(A) : (variant == 3) ? (int64_t)hipeig_tcoo_lds_bytes(A) : 0;
     key.csplit = (variant == 4) ? A->w_csplit + (fixed ? 1000 : 0) : 0;
     key.maxiter = maxiter; key.sigma = sigma; key.sign = sign; key.rtol = rtol;
+    key.csplit += fuse_kd ? 100000 : 0;
     const int gchunk = 18;
     if (!c->mr_graph || c->mr_graph_key_bytes != sizeof(key) || memcmp(c->mr_graph_key, &key, sizeof(key)) != 0) {
       if (c->mr_graph) { GTRACE("hipGraphExecDestroy"); hipGraphExecDestroy(c->mr_graph); c->mr_graph = nullptr; }
@@ -453,7 +546,8 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
                                                     : graph_mode == 2 ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
       capturing = true;
       int rc = 0;
-      for (int k = 0; k < gchunk && rc == 0; ++k) rc = enqueue_iteration(k);
+      for (int k = 0; k < gchunk && rc == 0; ++k) rc = enqueue_iteration(k, k == 0);
+      if (rc == 0) rc = enqueue_last_kd(gchunk - 1);
       if (rc == 0) rc = enqueue_check();
       GTRACE("hipStreamEndCapture");
       const hipError_t ce = hipStreamEndCapture(c->stream, &g);
@@ -482,10 +576,12 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
     int k = 0;
     while (k < maxiter) {
       const int kend = (k + chunk < maxiter) ? k + chunk : maxiter;
+      const int kfirst = k;
       for (; k < kend; ++k) {
-        const int rc = enqueue_iteration(k);
+        const int rc = enqueue_iteration(k, k == kfirst);
         if (rc) return rc;
       }
+      if (enqueue_last_kd(kend - 1)) return 1;
       HIPEIG_CHECK(hipGetLastError());
       if (enqueue_check()) return 1;
       HIPEIG_CHECK(hipStreamSynchronize(c->stream));
