@@ -124,14 +124,14 @@ scale_kernel(int64_t n, double alpha, int divide, const double* __restrict__ x, 
 
 extern "C" int hipeig_scale(hipeig_ctx* c, int64_t n, double alpha, const double* x, double* y) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 4)), dim3(HIPEIG_BLOCK), 0, c->stream, n, alpha, 0, x, y);
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_stream(n)), dim3(HIPEIG_BLOCK), 0, c->stream, n, alpha, 0, x, y);
   HIPEIG_CHECK(hipGetLastError());
   return 0;
 }
 
 extern "C" int hipeig_divide(hipeig_ctx* c, int64_t n, double alpha, const double* x, double* y) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 4)), dim3(HIPEIG_BLOCK), 0, c->stream, n, alpha, 1, x, y);
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_stream(n)), dim3(HIPEIG_BLOCK), 0, c->stream, n, alpha, 1, x, y);
   HIPEIG_CHECK(hipGetLastError());
   return 0;
 }
@@ -144,7 +144,7 @@ extern "C" int hipeig_normalize(hipeig_ctx* c, int64_t n, double* x, double* nor
   // la.norm then array /= norm (numpyVector.py:76-78): a true division, not a
   // multiplication by the reciprocal, to stay on the reference's rounding.
   if (n == 0) return 0;
-  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 4)), dim3(HIPEIG_BLOCK), 0, c->stream, n, nrm, 1, x, x);
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_stream(n)), dim3(HIPEIG_BLOCK), 0, c->stream, n, nrm, 1, x, x);
   HIPEIG_CHECK(hipGetLastError());
   return 0;
 }
@@ -167,7 +167,7 @@ axpby_kernel(int64_t n, double a, const double* __restrict__ x, double b, double
 
 extern "C" int hipeig_axpby(hipeig_ctx* c, int64_t n, double a, const double* x, double b, double* y) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 4)), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, x, b, y);
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_stream(n)), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, x, b, y);
   HIPEIG_CHECK(hipGetLastError());
   return 0;
 }
@@ -206,7 +206,7 @@ lincomb_kernel(int64_t n, int m, PtrTable tab, CoefTable cf, const double* __res
 static int lincomb_impl(hipeig_ctx* c, int64_t n, int k, const double* coeffs, const double* dcoef,
                         double dscale, const double* const* vecs, double* out, int accumulate_first) {
   if (n == 0) return 0;
-  const int g = grid_for(n, 2);
+  const int g = grid_stream(n);
   for (int j0 = 0; j0 < k; j0 += HIPEIG_MAX_COLS) {
     const int m = (k - j0 < HIPEIG_MAX_COLS) ? (k - j0) : HIPEIG_MAX_COLS;
     PtrTable tab;
@@ -289,7 +289,7 @@ extern "C" int hipeig_lincomb_block(hipeig_ctx* c, int64_t n, int m, int k, cons
   HIPEIG_CHECK(hipStreamSynchronize(c->stream));
   for (int j = 0; j < m; ++j) c->h_ptrs[j] = vecs[j];
   HIPEIG_CHECK(hipMemcpyAsync((void*)c->d_ptrs, c->h_ptrs, sizeof(double*) * m, hipMemcpyHostToDevice, c->stream));
-  const int g = grid_for(n, 2);
+  const int g = grid_for(n, 2);                       // the per-workgroup coefficient prologue wants long-lived workgroups (measured: n/512 workgroups 8 % slower)
   double* dcoef = c->d_partials;                      // free here: this call has no reduction
   double* cf = c->h_scalars;
   size_t cf_used = 0;
@@ -985,7 +985,7 @@ extern "C" int hipeig_orthonormalize(hipeig_ctx* c, int64_t n, int m, const doub
       hipLaunchKernelGGL(mgs_dots_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, x, Y[j], c->d_partials);
       HIPEIG_CHECK(hipGetLastError());
       if (finalize_to_host(c, g, 2, nullptr)) return 4;
-      hipLaunchKernelGGL(mgs_update_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, c->d_scalars, Y[j], x);
+      hipLaunchKernelGGL(mgs_update_kernel, dim3(grid_stream(n)), dim3(HIPEIG_BLOCK), 0, c->stream, n, c->d_scalars, Y[j], x);
       HIPEIG_CHECK(hipGetLastError());
     }
   } else {
@@ -1004,7 +1004,7 @@ extern "C" int hipeig_orthonormalize(hipeig_ctx* c, int64_t n, int m, const doub
   *innerprod = ip;
   if (ip > lindep) {
     *is_lindep = 0;
-    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 4)), dim3(HIPEIG_BLOCK), 0, c->stream, n, sqrt(ip), 1, x, x);
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_stream(n)), dim3(HIPEIG_BLOCK), 0, c->stream, n, sqrt(ip), 1, x, x);
     HIPEIG_CHECK(hipGetLastError());
   } else {
     *is_lindep = 1;

@@ -64,7 +64,7 @@ int hipeig_block_pack(hipeig_ctx* c, int K, int64_t n, int k, const double* cons
   if (n == 0) return 0;
   PtrTable8 t;
   for (int j = 0; j < BCOO_KMAX; ++j) t.p[j] = j < k ? cols[j] : nullptr;
-  const int g = grid_for(n * (K / 2), 2);
+  const int g = grid_stream(n * (K / 2) * 2);
   if (K == 4) hipLaunchKernelGGL(block_pack_kernel<4>, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, k, t, blk);
   else hipLaunchKernelGGL(block_pack_kernel<8>, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, k, t, blk);
   HIPEIG_CHECK(hipGetLastError());
@@ -76,7 +76,7 @@ int hipeig_block_unpack(hipeig_ctx* c, int K, int64_t n, int k, const double* bl
   if (n == 0) return 0;
   OutTable8 t;
   for (int j = 0; j < BCOO_KMAX; ++j) t.p[j] = j < k ? cols[j] : nullptr;
-  const int g = grid_for(n * (K / 2), 2);
+  const int g = grid_stream(n * (K / 2) * 2);
   if (K == 4) hipLaunchKernelGGL(block_unpack_kernel<4>, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, k, blk, t);
   else hipLaunchKernelGGL(block_unpack_kernel<8>, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, k, blk, t);
   HIPEIG_CHECK(hipGetLastError());

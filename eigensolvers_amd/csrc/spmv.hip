@@ -343,7 +343,7 @@ static int launch_spmv_pair(hipeig_ctx* c, hipeig_csr* A, double zr, double zi, 
     if (rc == 1) return 1;
     if (rc == 0 && !tcoow_ensure_parts(c, 2 * A->gather_len)) {
       double* xp = c->ytmp;
-      hipLaunchKernelGGL(pair_pack_kernel, dim3(grid_for(A->gather_len, 2)), dim3(HIPEIG_BLOCK), 0, c->stream,
+      hipLaunchKernelGGL(pair_pack_kernel, dim3(grid_stream(2 * A->gather_len)), dim3(HIPEIG_BLOCK), 0, c->stream,
                          A->gather_len, xr, xi, reinterpret_cast<double2*>(xp));
       TcooView t = hipeig_tcoow_view(A);
       t.idx = A->p_idx; t.val = A->p_val; t.off = A->p_off;
