@@ -649,6 +649,8 @@ static int build_tcoow_layout(hipeig_ctx* c, hipeig_csr* A, int pair) {
   int per_cu = (int)(163840 / ((pair ? 2 : 1) * rw * sizeof(double) + ((size_t)nwin + 2) * sizeof(uint32_t) + 256));
   if (per_cu > 2) per_cu = 2;                          // 1024-thread workgroups: at most 32 waves per CU
   if (per_cu < 1) per_cu = 1;
+  if (const char* e = getenv("HIPEIG_TCOOW_WG_PER_LAUNCH_CU")) per_cu = atoi(e);   // tuning knob: workgroups per CU in ONE launch (2 with full-height units: both sweeps in one launch, the second workgroup of a CU starts when its first ends)
+  HIPEIG_REQUIRE(per_cu >= 1 && per_cu <= 8, "HIPEIG_TCOOW_WG_PER_LAUNCH_CU out of range");
   if (pair) {
     A->p_nunits = (int)nunits; A->p_nwin = nwin; A->p_wbits = wbits; A->p_rw = (int)rw;
     A->p_wgs_per_sweep = per_cu * c->num_cu;
