@@ -306,6 +306,43 @@ def test_minres_tracks_the_oracle(hip, gapped4000, rtol, maxiter):
     assert np.linalg.norm(r) <= 1.05 * np.linalg.norm(ro) + 1e-13
 
 
+def test_minres_two_and_three_kernel_forms_agree_in_every_sweep_layout(hip, monkeypatch):
+    """KD riding in the epilogue of the next operator sweep (the default, two kernels per iteration) against KD as
+    its own kernel (HIPEIG_MINRES_FUSE_KD=0): same expressions in the same order, so iteration count, stop code and
+    the iterate agree - for every sweep layout the epilogue lives in: CSR-vector, CSR-stream, the two blocked
+    layouts, the fixed-point form, and a column-split blocked sweep whose epilogue runs in the combine launch.  The
+    oracle (SciPy's recurrences) is the referee for the count."""
+    from eigensolvers_amd.generators import gapped_csr_host, guess_vector
+    n = 300_000                                                # three column windows of the blocked layouts
+    Hh = gapped_csr_host(n, 16, seed=7)
+    b = guess_vector(n, 1)
+    b = b / np.linalg.norm(b)
+    xo, info, itn, istop = minres_ref(lambda v: 0.02 * v - Hh @ v, b, rtol=1e-8, maxiter=3000)
+
+    def solve(variant):
+        H = hip.HipCsrOperator.from_scipy(Hh)
+        H.set_variant(variant)
+        W = hip.HipVector.solve(H, hip.HipVector(b.copy(), _opts(3000, 1e-8)), 0.02)
+        return W.array, W.last_solve_stats
+
+    cases = [(1, None), (2, None), (3, None), (4, None), (5, None), (4, "3")]
+    for variant, csplit in cases:
+        if csplit:
+            monkeypatch.setenv("HIPEIG_TCOOW_CSPLIT", csplit)   # read when the layout is built
+        x2, s2 = solve(variant)
+        monkeypatch.setenv("HIPEIG_MINRES_FUSE_KD", "0")
+        x3, s3 = solve(variant)
+        monkeypatch.delenv("HIPEIG_MINRES_FUSE_KD")
+        if csplit:
+            monkeypatch.delenv("HIPEIG_TCOOW_CSPLIT")
+        assert s2["iterations"] == s3["iterations"] == itn and s2["istop"] == s3["istop"] == istop, (variant, csplit)
+        scale = np.linalg.norm(xo)
+        assert np.linalg.norm(x2 - x3) <= 1e-7 * scale, (variant, csplit)      # variant 4 adds a row in varying order
+        assert np.linalg.norm(x2 - xo) <= 1e-6 * scale, (variant, csplit)
+        if variant in (1, 2, 3, 5) and not csplit:                             # fixed summation order: bit for bit
+            np.testing.assert_array_equal(x2, x3)
+
+
 def test_minres_graph_replay_is_bit_identical(hip, gapped4000, monkeypatch):
     """HIPEIG_GRAPH=1 (read when a context is created): the captured 18-iteration chunk replayed for
     every chunk and every solve gives exactly the plain-launch result; changing the tolerance or the
