@@ -187,16 +187,20 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* lds) {
 // Every thread of the workgroup obtains the fixed-order sum of p[0..count) (count <=
 // HIPEIG_MAX_PARTIALS).  Used in kernel prologues so that a reduction never needs its own
 // launch or a host round trip; every workgroup computes the identical value.
+// The summation tree is that of a 256-thread workgroup whatever the launch shape (the 1024-thread sweep kernels
+// leave their upper waves out), so a scalar does not depend on WHICH kernel's prologue reduces it.
 __device__ __forceinline__ double block_sum_partials(const double* __restrict__ p, int count,
                                                      double* lds) {
+  const int nt = blockDim.x < HIPEIG_BLOCK ? (int)blockDim.x : HIPEIG_BLOCK;
   double a = 0.0;
-  for (int i = threadIdx.x; i < count; i += blockDim.x) a += p[i];
+  if ((int)threadIdx.x < nt)
+    for (int i = threadIdx.x; i < count; i += nt) a += p[i];
   a = wave_reduce_sum(a);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) lds[wid] = a;
   __syncthreads();
   double r = lds[0];
-  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r += lds[w];
+  for (int w = 1; w < (nt >> 6); ++w) r += lds[w];
   __syncthreads();
   return r;
 }

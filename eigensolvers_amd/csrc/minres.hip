@@ -40,8 +40,11 @@ size_t hipeig_tcoo_lds_bytes(const hipeig_csr* A);
 struct MinresKd {
   double s_old, oldeps, delta, denom, phi;
   __device__ __forceinline__ void apply(double r2old, double a1, double a2, double& wn, double& xv) const {
-    wn = (s_old * r2old - oldeps * a1 - delta * a2) * denom;
-    xv += phi * wn;
+    // spelled out with explicit fused operations (and contraction off) so that every instantiation - the stand-alone
+    // kernel and the epilogue of each sweep layout - rounds identically: the two forms then agree bit for bit
+#pragma clang fp contract(off)
+    wn = fma(-delta, a2, fma(-oldeps, a1, s_old * r2old)) * denom;
+    xv = fma(phi, wn, xv);
   }
 };
 
