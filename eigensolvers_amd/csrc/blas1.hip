@@ -778,9 +778,9 @@ scale_by_inv_norm_kernel(int64_t n, const double* __restrict__ ss, double* __res
 
 // Single-GPU form of the step: the update with column j and the dot product with column j+1 share one
 // pass (and one launch), the two norms ride on the first and the last pass: m + 2 launches and three vector
-// passes per column instead of 2m + 5 launches and five passes.  Grid, element-to-thread assignment and
-// reduction trees are those of the kernels above, so the numbers are bit-identical to the unfused path
-// (which a partitioned run keeps, because it needs an all-reduce between a dot and its update).
+// passes per column instead of 2m + 5 launches and five passes.  (A partitioned run keeps the unfused path: it
+// needs an all-reduce between a dot and its update.  The two paths assign elements to threads differently, so their
+// coefficients agree to rounding, not bit for bit.)
 // Workspace (doubles, g = grid): two phase buffers of 3g - [re | im | ||w||^2 after] - used alternately, and
 // g for ||w||^2 before at offset 6g.
 template <bool PAIR>
@@ -811,6 +811,54 @@ arnoldi_first_kernel(int64_t n, const double* __restrict__ a, const double* __re
   }
 }
 
+// The kernel GCROT's orthogonalisation lives in (63 % of the device time of a complex contour solve at N = 1e6,
+// rocprofv3 of tools/experiments/gcrot_complex_solve.py).  16-byte accesses, two of them per stream in flight per
+// thread and every load of a trip issued before its first store; the column being subtracted is read for the last
+// time here (non-temporal), the next column stays cached for the next launch.
+typedef double arn_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 arn_ld(const double* p, int64_t i2, bool nt) {
+  if (nt) { const arn_d2 v = __builtin_nontemporal_load(reinterpret_cast<const arn_d2*>(p) + i2); return make_double2(v.x, v.y); }
+  return reinterpret_cast<const double2*>(p)[i2];
+}
+
+template <bool PAIR>
+struct ArnoldiLane {                  // one 16-byte slot (two consecutive elements) of every stream
+  double2 p, q, a2p, a2q, x, y;
+  __device__ __forceinline__ void load(int64_t i2, const double* a, const double* b, const double* a2, const double* b2,
+                                       const double* wre, const double* wim, int last) {
+    p = arn_ld(a, i2, true);
+    if (PAIR) q = arn_ld(b, i2, true);
+    if (!last) { a2p = arn_ld(a2, i2, false); if (PAIR) a2q = arn_ld(b2, i2, false); }
+    x = arn_ld(wre, i2, false);
+    if (PAIR) y = arn_ld(wim, i2, false);
+  }
+  __device__ __forceinline__ void update(double cr, double ci) {
+    if (PAIR) {
+      x.x = x.x - (cr * p.x - ci * q.x); y.x = y.x - (cr * q.x + ci * p.x);       // w -= c * v
+      x.y = x.y - (cr * p.y - ci * q.y); y.y = y.y - (cr * q.y + ci * p.y);
+    } else {
+      x.x = fma(-cr, p.x, x.x); x.y = fma(-cr, p.y, x.y);
+    }
+  }
+  __device__ __forceinline__ void store(int64_t i2, double* wre, double* wim) const {
+    reinterpret_cast<double2*>(wre)[i2] = x;
+    if (PAIR) reinterpret_cast<double2*>(wim)[i2] = y;
+  }
+  __device__ __forceinline__ void accumulate(int last, double& re, double& im, double& ss) const {
+    if (last) {
+      ss = fma(x.x, x.x, ss); ss = fma(x.y, x.y, ss);
+      if (PAIR) { ss = fma(y.x, y.x, ss); ss = fma(y.y, y.y, ss); }
+    } else {
+      re = fma(a2p.x, x.x, re); re = fma(a2p.y, x.y, re);
+      if (PAIR) {
+        re = fma(a2q.x, y.x, re); re = fma(a2q.y, y.y, re);
+        im = fma(a2p.x, y.x, im); im = fma(-a2q.x, x.x, im);
+        im = fma(a2p.y, y.y, im); im = fma(-a2q.y, x.y, im);
+      }
+    }
+  }
+};
+
 template <bool PAIR>
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
 arnoldi_column_kernel(int64_t n, const double* __restrict__ pin, double* __restrict__ pout,
@@ -819,19 +867,42 @@ arnoldi_column_kernel(int64_t n, const double* __restrict__ pin, double* __restr
                       double* __restrict__ wre, double* __restrict__ wim, double* __restrict__ coef_out) {
   __shared__ double lds[4];
   const int g = gridDim.x;
+  const int64_t n2 = n >> 1;
+  const int64_t stride = (int64_t)g * blockDim.x;
+  // the first trip's loads do not depend on the coefficient: issue them BEFORE the prologue reduces the previous
+  // launch's partial sums, so that the reduction (L2 reads + two barriers) hides behind their HBM latency
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  ArnoldiLane<PAIR> L0, L1;
+  bool has0 = i < n2, has1 = i + stride < n2;
+  if (has0) L0.load(i, a, b, a2, b2, wre, wim, last);
+  if (has1) L1.load(i + stride, a, b, a2, b2, wre, wim, last);
   const double cr = block_sum_partials(pin, g, lds);
   const double ci = PAIR ? block_sum_partials(pin + g, g, lds) : 0.0;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     coef_out[0] = cr;
     if (PAIR) coef_out[1] = ci;
   }
-  const int64_t stride = (int64_t)g * blockDim.x;
   double re = 0.0, im = 0.0, ss = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  while (has0) {
+    L0.update(cr, ci);
+    L0.store(i, wre, wim);
+    L0.accumulate(last, re, im, ss);
+    if (has1) {
+      L1.update(cr, ci);
+      L1.store(i + stride, wre, wim);
+      L1.accumulate(last, re, im, ss);
+    }
+    i += 2 * stride;
+    has0 = i < n2; has1 = i + stride < n2;
+    if (has0) L0.load(i, a, b, a2, b2, wre, wim, last);
+    if (has1) L1.load(i + stride, a, b, a2, b2, wre, wim, last);
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {           // odd length: the last element
+    const int64_t i = n - 1;
     double x, y = 0.0;
     if (PAIR) {
       const double p = a[i], q = b[i];
-      x = wre[i] - (cr * p - ci * q);              // w -= c * v
+      x = wre[i] - (cr * p - ci * q);
       y = wim[i] - (cr * q + ci * p);
       wre[i] = x; wim[i] = y;
     } else {
