@@ -950,9 +950,104 @@ arnoldi_last_kernel(int64_t n, const double* __restrict__ p_before, const double
   }
 }
 
+// Short vectors (the reference's own problem sizes: n = 100 ... 4000): the whole step - norm, the sequential sweep over
+// all m columns, norm, scaling - in ONE workgroup and ONE launch, the vector being orthogonalised held in registers.
+// At these lengths a launch per column is pure dispatch latency (~5 us each, 20-60 columns per step); a workgroup-wide
+// reduction costs two barriers.  Same order of operations as the column kernels (sequential MGS, SciPy's _fgmres).
+#define ARN_SMALL_THREADS 1024
+#define ARN_SMALL_E 8                       // elements per thread: n <= 8192 (16 would spill the pair form)
+#define ARN_SMALL_MAXCOLS 64
+struct ArnSmallCols { const double* re[ARN_SMALL_MAXCOLS]; const double* im[ARN_SMALL_MAXCOLS]; };
+
+// sums of (a, b) over the workgroup, returned to every thread; fixed tree.  lds: 2 x 16 doubles
+__device__ __forceinline__ void arn_small_reduce2(double& a, double& b, double* lds) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();                                   // the previous reduction's readers are done with lds
+  if (lane == 0) { lds[wid] = a; lds[16 + wid] = b; }
+  __syncthreads();
+  a = lds[0]; b = lds[16];
+  for (int w = 1; w < ARN_SMALL_THREADS / 64; ++w) { a += lds[w]; b += lds[16 + w]; }
+}
+
+template <bool PAIR>
+__global__ void __launch_bounds__(ARN_SMALL_THREADS)
+arnoldi_small_kernel(int n, int m, ArnSmallCols V, double* __restrict__ wre, double* __restrict__ wim, double* __restrict__ dres) {
+  __shared__ double lds[32];
+  const int W = PAIR ? 2 : 1;
+  double x[ARN_SMALL_E], y[ARN_SMALL_E];
+  double ss = 0.0, zero = 0.0;
+#pragma unroll
+  for (int e = 0; e < ARN_SMALL_E; ++e) {
+    const int i = threadIdx.x + e * ARN_SMALL_THREADS;
+    x[e] = i < n ? wre[i] : 0.0;
+    y[e] = (PAIR && i < n) ? wim[i] : 0.0;
+    ss = fma(x[e], x[e], ss);
+    if (PAIR) ss = fma(y[e], y[e], ss);
+  }
+  arn_small_reduce2(ss, zero, lds);
+  if (threadIdx.x == 0) dres[0] = ss;
+  for (int j = 0; j < m; ++j) {
+    const double* __restrict__ vr = V.re[j];
+    const double* __restrict__ vi = PAIR ? V.im[j] : nullptr;
+    double re = 0.0, im = 0.0;
+#pragma unroll
+    for (int e = 0; e < ARN_SMALL_E; ++e) {
+      const int i = threadIdx.x + e * ARN_SMALL_THREADS;
+      const double p = i < n ? vr[i] : 0.0;
+      const double q = (PAIR && i < n) ? vi[i] : 0.0;
+      re = fma(p, x[e], re);
+      if (PAIR) { re = fma(q, y[e], re); im = fma(p, y[e], im); im = fma(-q, x[e], im); }
+    }
+    arn_small_reduce2(re, im, lds);                  // c = conj(v) . w, the same value in every thread
+    if (threadIdx.x == 0) { dres[1 + W * j] = re; if (PAIR) dres[2 + W * j] = im; }
+#pragma unroll
+    for (int e = 0; e < ARN_SMALL_E; ++e) {          // the column again (L1 / L2 at these lengths): registers hold only w
+      const int i = threadIdx.x + e * ARN_SMALL_THREADS;
+      const double p = i < n ? vr[i] : 0.0;
+      const double q = (PAIR && i < n) ? vi[i] : 0.0;
+      if (PAIR) {
+        const double nx = x[e] - (re * p - im * q);              // w -= c * v
+        y[e] = y[e] - (re * q + im * p);
+        x[e] = nx;
+      } else {
+        x[e] = fma(-re, p, x[e]);
+      }
+    }
+  }
+  double sa = 0.0;
+  zero = 0.0;
+#pragma unroll
+  for (int e = 0; e < ARN_SMALL_E; ++e) { sa = fma(x[e], x[e], sa); if (PAIR) sa = fma(y[e], y[e], sa); }
+  arn_small_reduce2(sa, zero, lds);
+  if (threadIdx.x == 0) dres[1 + W * m] = sa;
+  const double alpha = 1.0 / sqrt(sa);
+  const bool scale = isfinite(alpha);
+#pragma unroll
+  for (int e = 0; e < ARN_SMALL_E; ++e) {
+    const int i = threadIdx.x + e * ARN_SMALL_THREADS;
+    if (i < n) {
+      wre[i] = scale ? x[e] * alpha : x[e];
+      if (PAIR) wim[i] = scale ? y[e] * alpha : y[e];
+    }
+  }
+}
+
 template <bool PAIR>
 static int arnoldi_fused(hipeig_ctx* c, int64_t n, int m, const double* const* Vre, const double* const* Vim,
                          double* wre, double* wim, double* dres) {
+  static const bool small_on = !(getenv("HIPEIG_ARNOLDI_SMALL") && atoi(getenv("HIPEIG_ARNOLDI_SMALL")) == 0);
+  if (small_on && n <= (int64_t)ARN_SMALL_THREADS * ARN_SMALL_E && m <= ARN_SMALL_MAXCOLS) {
+    ArnSmallCols V;
+    for (int j = 0; j < ARN_SMALL_MAXCOLS; ++j) {
+      V.re[j] = j < m ? Vre[j] : nullptr;
+      V.im[j] = (PAIR && j < m) ? Vim[j] : nullptr;
+    }
+    hipLaunchKernelGGL((arnoldi_small_kernel<PAIR>), dim3(1), dim3(ARN_SMALL_THREADS), 0, c->stream, (int)n, m, V, wre, wim, dres);
+    HIPEIG_CHECK(hipGetLastError());
+    return 0;
+  }
   const int g = grid_for(n, 4);
   const int W = PAIR ? 2 : 1;
   double* P = c->d_partials;
