@@ -26,10 +26,14 @@ def timed(fn, reps):
 reps = 20 if N > 2_000_000 else 100
 out = {"N": N, "nnz": int(H.nnz), "z": [z.real, z.imag]}
 out["single_product_ms"] = round(timed(lambda: H.apply_shifted(z.real, xr._buf, y1), reps), 4)
+forced = os.environ.get("HIPEIG_PAIR_SWEEP")          # HIPEIG_PAIR_SWEEP=1 from outside: time the pair sweep where the rule would not take it
 os.environ["HIPEIG_PAIR_SWEEP"] = "0"
 out["two_sweeps_ms"] = round(timed(lambda: H.apply_shifted_pair(z, xr._buf, xi._buf, yr, yi), reps), 4)
 a = ea.HipVector(yr).array.copy(), ea.HipVector(yi).array.copy()
-del os.environ["HIPEIG_PAIR_SWEEP"]
+if forced is None:
+    del os.environ["HIPEIG_PAIR_SWEEP"]
+else:
+    os.environ["HIPEIG_PAIR_SWEEP"] = forced
 out["pair_sweep_ms"] = round(timed(lambda: H.apply_shifted_pair(z, xr._buf, xi._buf, yr, yi), reps), 4)
 out["pair_info"] = H.pair_info()
 b = ea.HipVector(yr).array, ea.HipVector(yi).array
