@@ -575,7 +575,10 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
       if (h->done) break;
     }
   } else {
-    const int chunk = 16;
+    // iterations between two looks at the state record (check kernel + copy-back + host sync: ~70 us at N = 1e6, where
+    // an iteration takes 140 us).  Kernels launched past the stopping iteration return at once (~5 us each), so a longer
+    // chunk wastes at most that; a partitioned run keeps 16 (its check costs a collective on every rank).
+    const int chunk = dist ? 16 : 32;
     int k = 0;
     while (k < maxiter) {
       const int kend = (k + chunk < maxiter) ? k + chunk : maxiter;
