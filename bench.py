@@ -4,9 +4,9 @@ dominates the inexact-Lanczos shift-and-invert inner loop, at BASELINE.json's me
 configuration (random-sparse Hermitian, N = 1e7, nnz/row ~ 64), plus Lanczos iterations/s
 on the same operator.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]            (N > 1: starts its own N ranks, no launcher needed)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W  (a launcher's RANK / WORLD_SIZE are honoured)
 
 One process per GPU.  With N > 1 the SAME N = 1e7 operator is row-partitioned over the ranks
 (strong scaling: total work fixed); every step is an RCCL all-gather of the operand slice
@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--lanczos-maxit", type=int, default=4)
     ap.add_argument("--lanczos-econv", type=float, default=1e-10)
     ap.add_argument("--cpu-lanczos-n", type=int, default=100_000, help="size of the CPU Lanczos baseline instance (~15 s of one core)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, run the TCP rendezvous and an all-gather of the rank ids, print the JSON line, touch no GPU")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-spawned ranks are stopped after this many seconds")
     return ap.parse_args()
 
 
@@ -59,8 +62,29 @@ def global_bytes(N, nnz):
     return nnz * 12 + (N + 1) * 4 + 8 * N + 8 * N
 
 
+def rendezvous_only(a, result):
+    """The multi-rank start-up without a GPU: every rank joins the TCP group, hands its rank id round and checks what
+    it got back; rank 0 prints the line.  What `pytest -m "not gpu"` runs to see `bench.py --gpus 2` start plainly."""
+    from eigensolvers_amd import distributed as D
+    rank, world, local_rank = D.world_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
+    grp = D.tcp_group(rank, world, timeout=60.0)
+    seen = [int(b.decode()) for b in grp.allgather(str(rank).encode())]
+    uid = D.exchange_bytes(bytes(range(128)) if rank == 0 else b"", 128, rank, world)
+    grp.barrier()
+    ok = seen == list(range(world)) and uid == bytes(range(128))
+    if rank == 0:
+        result["line"] = json.dumps({"rendezvous": "ok" if ok else "failed", "n_ranks_seen": len(seen), "n_gpus": world,
+                                     "launcher": os.environ.get("HIPEIG_LAUNCHER", "external")})
+    if not ok:
+        raise SystemExit(3)
+
+
 def main(result):
     a = parse()
+    if a.rendezvous_only:
+        return rendezvous_only(a, result)
     import ctypes as C
     import numpy as np
     import eigensolvers_amd as ea
@@ -68,7 +92,7 @@ def main(result):
 
     rank, world, local_rank = D.world_from_env()
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
     force = os.environ.get("HIPEIG_FORCE_COLLECTIVES", "0") not in ("", "0")     # rehearse the RCCL path on one rank
     try:
         ctx = ea.HipContext(local_rank)
@@ -264,6 +288,17 @@ def main(result):
 
 
 if __name__ == "__main__":
+    _a = parse()
+    if _a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly: this process becomes the launcher - it spawns one rank per GPU BEFORE anything here has
+        # touched a GPU, relays rank 0's JSON line and exits non-zero if any rank did
+        from eigensolvers_amd.distributed import launch_local
+        _rc, _out = launch_local([os.path.abspath(__file__)] + sys.argv[1:], _a.gpus, timeout=_a.launch_timeout,
+                                 env_extra={"HIPEIG_LAUNCHER": "bench.py"})
+        _lines = [ln for ln in _out.splitlines() if ln.startswith("{")]
+        if _lines:
+            print(_lines[-1], flush=True)
+        sys.exit(_rc if _rc else (0 if _lines else 5))
     # Native libraries (gloo, RCCL) write banners to file descriptor 1; keep stdout to the one JSON
     # line by running everything with fd 1 pointed at stderr and printing the result afterwards.
     from eigensolvers_amd.distributed import stdout_to_stderr

@@ -38,6 +38,13 @@ SIGNATURES = {
     "hipeig_comm_stats": [_P, _I64P],
     "hipeig_comm_set_partitioned": [_P, C.c_int],
     "hipeig_vec_allreduce": [_P, _P, C.c_int64],
+    "hipeig_direct_alloc": [_P, _I64, _P],
+    "hipeig_direct_attach": [_P, _P],
+    "hipeig_comm_set_gather_backend": [_P, C.c_int],
+    "hipeig_comm_gather_info": [_P, _I64P],
+    "hipeig_phase_timing": [_P, C.c_int],
+    "hipeig_phase_get": [_P, _DP],
+    "hipeig_comm_bench_allreduce": [_P, C.c_int, C.c_int, _DP],
     "hipeig_loopback_group_create": [C.c_int, C.POINTER(C.c_void_p)],
     "hipeig_loopback_group_destroy": [_P],
     "hipeig_comm_init_loopback": [_P, _P, C.c_int],
@@ -67,6 +74,7 @@ SIGNATURES = {
     "hipeig_csr_generate": [_P, _I64, _I64, _I64, C.c_int, C.c_uint64, _D, C.c_uint32, _DP, C.c_int, _PP],
     "hipeig_csr_destroy": [_P, _P],
     "hipeig_csr_info": [_P, _I64P],
+    "hipeig_csr_layout_info": [_P, _I64P],
     "hipeig_csr_download": [_P, _P, _I64P, _I32P, _DP],
     "hipeig_csr_set_variant": [_P, C.c_int],
     "hipeig_csr_set_reproducible": [_P, C.c_int],

@@ -143,6 +143,8 @@ static void comm_flags_from_env(hipeig_ctx* c, int nranks) {
   // HIPEIG_OVERLAP=0 turns the all-gather / local-window overlap off (default on)
   const char* ov = getenv("HIPEIG_OVERLAP");
   c->overlap = c->collectives && !(ov && atoi(ov) == 0);
+  const char* gc = getenv("HIPEIG_GATHER_CHUNKS");          // 0 / unset: automatic (pick_gather_chunks)
+  c->gather_chunks = gc ? atoi(gc) : 0;
 }
 
 extern "C" int hipeig_comm_init_loopback(hipeig_ctx* c, void* group, int rank) {
@@ -234,7 +236,10 @@ extern "C" int hipeig_comm_init(hipeig_ctx* c, int nranks, int rank, const void*
   return 0;
 }
 
+int hipeig_direct_destroy(hipeig_ctx* c);
+
 extern "C" int hipeig_comm_destroy(hipeig_ctx* c) {
+  if (c->direct) hipeig_direct_destroy(c);
   if (c->comm) {
     hipStreamSynchronize(c->stream);
     g_rccl.CommDestroy((ncclComm_t)c->comm);
@@ -289,11 +294,44 @@ extern "C" int hipeig_vec_allreduce(hipeig_ctx* c, double* v, int64_t n) {
   return 0;
 }
 
-// Gather the row counts of every rank (host result in ctx->row_counts) and size the
-// gathered-operand buffer: rank r's slice lives at x_full + r*stride, stride = max count.
-int hipeig_comm_setup_rows(hipeig_ctx* c, int64_t nrows_local, int64_t* stride_out) {
+// Chunks the operand exchange is cut into: HIPEIG_GATHER_CHUNKS, else 2 when the slices are long enough for the sweep
+// of one chunk's column windows to hide the transfer of the next (>= 4 windows of 2^17 columns per chunk) and the
+// overlap is on, else 1.
+static int pick_gather_chunks(const hipeig_ctx* c, int64_t max_rows) {
+  int n = c->gather_chunks;
+  if (n <= 0) n = (c->overlap && c->nranks > 1 && max_rows >= ((int64_t)8 << 17)) ? 2 : 1;
+  if (n > HIPEIG_GATHER_MAX_CHUNKS) n = HIPEIG_GATHER_MAX_CHUNKS;
+  while (n > 1 && max_rows / n < 16) --n;
+  return n;
+}
+
+// Layout for slices of at most max_rows rows (the same on every rank).
+void hipeig_gather_layout(const hipeig_ctx* c, int64_t max_rows, GatherLayout* gl) {
+  const int nch = pick_gather_chunks(c, max_rows);
+  int64_t h = (max_rows + nch - 1) / nch;
+  const int64_t W = (int64_t)1 << 17;                       // the widest column window of the blocked sweeps
+  if (h >= 4 * W) h = (h + W - 1) / W * W;                   // slices start on window boundaries: every window has one owner
+  else h = (h + 15) / 16 * 16;                               // whole 128-byte lines
+  if (h < 16) h = 16;
+  gl->nranks = c->nranks; gl->nchunks = nch; gl->h = h;
+  int64_t pos = 0;
+  for (int k = 0; k < nch; ++k) { gl->cbase[k] = pos; pos += (int64_t)c->nranks * gl->cstride(k); }
+  for (int k = nch; k <= HIPEIG_GATHER_MAX_CHUNKS; ++k) gl->cbase[k] = pos;
+}
+
+int hipeig_direct_reserve(hipeig_ctx* c, int64_t doubles);     // comm_direct.hip
+int hipeig_direct_begin(hipeig_ctx* c, const GatherLayout& gl, int64_t n_local);
+int hipeig_direct_wait_chunk(hipeig_ctx* c, const GatherLayout& gl, int chunk);
+double* hipeig_direct_next_buffer(hipeig_ctx* c);
+double* hipeig_direct_current_buffer(hipeig_ctx* c);
+
+// Gather the row counts of every rank (host result in ctx->row_counts), fix the layout of the gathered operand for
+// slices of that size and make sure the buffer holds it.
+int hipeig_comm_setup_rows(hipeig_ctx* c, int64_t nrows_local, GatherLayout* gl) {
   if (!c->collectives) {
-    *stride_out = nrows_local;
+    gl->nranks = 1; gl->nchunks = 1; gl->h = nrows_local > 16 ? nrows_local : 16;
+    gl->cbase[0] = 0;
+    for (int k = 1; k <= HIPEIG_GATHER_MAX_CHUNKS; ++k) gl->cbase[k] = gl->h + HIPEIG_SLOT_DOUBLES;
     return 0;
   }
   int64_t* d = (int64_t*)c->d_scalars;
@@ -304,32 +342,88 @@ int hipeig_comm_setup_rows(hipeig_ctx* c, int64_t nrows_local, int64_t* stride_o
   if (coll_allgather(c, d + c->rank, d, 1, NCCL_INT64, c->stream)) return 4;
   HIPEIG_CHECK(hipMemcpyAsync(c->row_counts, d, sizeof(int64_t) * c->nranks, hipMemcpyDeviceToHost, c->stream));
   HIPEIG_CHECK(hipStreamSynchronize(c->stream));
-  int64_t stride = 0;
-  for (int r = 0; r < c->nranks; ++r) stride = c->row_counts[r] > stride ? c->row_counts[r] : stride;
-  const int64_t need = stride * c->nranks;
+  int64_t max_rows = 0;
+  for (int r = 0; r < c->nranks; ++r) max_rows = c->row_counts[r] > max_rows ? c->row_counts[r] : max_rows;
+  hipeig_gather_layout(c, max_rows, gl);
+  const int64_t need = gl->total();
   if (need > c->x_full_n) {
+    HIPEIG_CHECK(hipStreamSynchronize(c->comm_stream));
     if (c->x_full) HIPEIG_CHECK(hipFree(c->x_full));
+    c->x_full = nullptr; c->x_full_n = 0;
     HIPEIG_CHECK(hipMalloc((void**)&c->x_full, (size_t)need * sizeof(double)));
     HIPEIG_CHECK(hipMemsetAsync(c->x_full, 0, (size_t)need * sizeof(double), c->stream));
     c->x_full_n = need;
   }
-  *stride_out = stride;
+  if (c->direct && hipeig_direct_reserve(c, need)) return 4;
   return 0;
 }
 
-// All-gather of the operand: every rank contributes its slice, in place inside x_full.
-int hipeig_allgather_x(hipeig_ctx* c, const double* x_local, int64_t n_local, int64_t stride,
-                       const double** x_full_out) {
+// The buffer the NEXT operand exchange of this context fills (the direct backend alternates between two).
+static double* gather_buffer_next(hipeig_ctx* c) { return (c->direct && c->gather_backend == 1) ? hipeig_direct_next_buffer(c) : c->x_full; }
+static double* gather_buffer_current(hipeig_ctx* c) { return (c->direct && c->gather_backend == 1) ? hipeig_direct_current_buffer(c) : c->x_full; }
+
+// This rank's scalar slot inside the buffer of the NEXT exchange: what a kernel stores there before
+// hipeig_allgather_x[_begin] travels with the operand and is found at gathered + gl.slot(r) on every rank.
+double* hipeig_gather_slot(hipeig_ctx* c, const GatherLayout& gl) {
+  if (!c->collectives) return nullptr;
+  return gather_buffer_next(c) + gl.slot(c->rank);
+}
+
+// Phase events of a partitioned product (hipeig_phase_timing): 0 begin, 1 local sweep done, 2 first remote launch may
+// start, 3 product done (compute stream); 4 exchange starts, 5 exchange done (communication stream).
+static inline void phase_mark(hipeig_ctx* c, int k, hipStream_t s) {
+  if (c->phase_timing) hipEventRecord(c->ev_ph[k], s);
+}
+void hipeig_phase_mark(hipeig_ctx* c, int k) { phase_mark(c, k, c->stream); }
+
+// Start the operand exchange: the slice goes into its places in the gathered buffer on the compute stream, then the
+// communication stream moves chunk after chunk (one collective each, in place) and records an event per chunk.
+int hipeig_allgather_x_begin(hipeig_ctx* c, const GatherLayout& gl, const double* x_local, int64_t n_local) {
+  HIPEIG_REQUIRE(c->collectives, "no communicator");
+  HIPEIG_REQUIRE(gl.nranks == c->nranks && n_local <= gl.h * gl.nchunks && gl.total() <= c->x_full_n,
+                 "operand buffer smaller than the partition");
+  phase_mark(c, 0, c->stream);
+  double* buf = gather_buffer_next(c);
+  for (int k = 0; k < gl.nchunks; ++k) {
+    const int64_t lo = (int64_t)k * gl.h, hi = (lo + gl.h < n_local) ? lo + gl.h : n_local;
+    if (hi > lo)
+      HIPEIG_CHECK(hipMemcpyAsync(buf + gl.pos(c->rank, lo), x_local + lo, (size_t)(hi - lo) * sizeof(double),
+                                  hipMemcpyDeviceToDevice, c->stream));
+  }
+  HIPEIG_CHECK(hipEventRecord(c->ev_x, c->stream));
+  HIPEIG_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_x, 0));
+  phase_mark(c, 4, c->comm_stream);
+  if (c->direct && c->gather_backend == 1) {
+    if (hipeig_direct_begin(c, gl, n_local)) return 4;
+  } else {
+    for (int k = 0; k < gl.nchunks; ++k) {
+      double* region = buf + gl.cbase[k];
+      if (coll_allgather(c, region + (int64_t)c->rank * gl.cstride(k), region, (size_t)gl.cstride(k), NCCL_FLOAT64, c->comm_stream)) return 4;
+      HIPEIG_CHECK(hipEventRecord(c->ev_chunk[k], c->comm_stream));
+    }
+  }
+  phase_mark(c, 5, c->comm_stream);
+  return 0;
+}
+
+// The compute stream waits until chunk `chunk` (and every earlier one) of the exchange begun last has arrived.
+int hipeig_allgather_x_wait_chunk(hipeig_ctx* c, const GatherLayout& gl, int chunk) {
+  if (c->direct && c->gather_backend == 1) return hipeig_direct_wait_chunk(c, gl, chunk);
+  HIPEIG_CHECK(hipStreamWaitEvent(c->stream, c->ev_chunk[chunk], 0));
+  return 0;
+}
+
+const double* hipeig_gathered(hipeig_ctx* c) { return gather_buffer_current(c); }
+
+// Whole exchange, compute stream ordered after it.
+int hipeig_allgather_x(hipeig_ctx* c, const GatherLayout& gl, const double* x_local, int64_t n_local, const double** x_full_out) {
   if (!c->collectives) {
     *x_full_out = x_local;
     return 0;
   }
-  HIPEIG_REQUIRE(stride >= n_local && stride * c->nranks <= c->x_full_n, "operand buffer smaller than the partition");
-  double* mine = c->x_full + (int64_t)c->rank * stride;
-  HIPEIG_CHECK(hipMemcpyAsync(mine, x_local, (size_t)n_local * sizeof(double),
-                              hipMemcpyDeviceToDevice, c->stream));
-  if (coll_allgather(c, mine, c->x_full, (size_t)stride, NCCL_FLOAT64, c->stream)) return 4;
-  *x_full_out = c->x_full;
+  if (hipeig_allgather_x_begin(c, gl, x_local, n_local)) return 4;
+  if (hipeig_allgather_x_wait_chunk(c, gl, gl.nchunks - 1)) return 4;
+  *x_full_out = gather_buffer_current(c);
   return 0;
 }
 
@@ -340,24 +434,96 @@ int hipeig_allgather_f64(hipeig_ctx* c, const double* send, double* recv, size_t
   return coll_allgather(c, send, recv, count, NCCL_FLOAT64, c->stream);
 }
 
-// Split form of the operand all-gather: `begin` issues the copy + ncclAllGather on the
-// communication stream (ordered after everything already queued on the compute stream),
-// `end` makes the compute stream wait for it.  Between the two the caller may launch work that
-// reads only x_local.
-int hipeig_allgather_x_begin(hipeig_ctx* c, const double* x_local, int64_t n_local, int64_t stride) {
-  HIPEIG_REQUIRE(c->collectives, "no communicator");
-  HIPEIG_REQUIRE(stride >= n_local && stride * c->nranks <= c->x_full_n, "operand buffer smaller than the partition");
-  double* mine = c->x_full + (int64_t)c->rank * stride;
-  HIPEIG_CHECK(hipEventRecord(c->ev_x, c->stream));
-  HIPEIG_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_x, 0));
-  HIPEIG_CHECK(hipMemcpyAsync(mine, x_local, (size_t)n_local * sizeof(double), hipMemcpyDeviceToDevice, c->comm_stream));
-  if (coll_allgather(c, mine, c->x_full, (size_t)stride, NCCL_FLOAT64, c->comm_stream)) return 4;
-  HIPEIG_CHECK(hipEventRecord(c->ev_comm, c->comm_stream));
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+block_rows_copy_kernel(int64_t n16, const double2* __restrict__ src, double2* __restrict__ dst) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
+// Interleaved block operand of width K: the layout of the single-vector exchange with every position K doubles wide
+// (chunk c at cbase[c]*K, per-rank stride cstride(c)*K; the slot of a rank is the K*HIPEIG_SLOT_DOUBLES doubles behind
+// its rows of the last chunk: K scalars per rank ride along).  On the compute stream, one collective per chunk.
+int hipeig_block_reserve(hipeig_ctx* c, const GatherLayout& gl, int K) {
+  if (!c->collectives) return 0;
+  const int64_t need = gl.total() * K;
+  if (c->xb_full_n < need) {
+    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+    if (c->xb_full) HIPEIG_CHECK(hipFree(c->xb_full));
+    c->xb_full = nullptr; c->xb_full_n = 0;
+    HIPEIG_CHECK(hipMalloc((void**)&c->xb_full, (size_t)need * sizeof(double)));
+    HIPEIG_CHECK(hipMemsetAsync(c->xb_full, 0, (size_t)need * sizeof(double), c->stream));
+    c->xb_full_n = need;
+  }
   return 0;
 }
 
-int hipeig_allgather_x_end(hipeig_ctx* c, const double** x_full_out) {
-  HIPEIG_CHECK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
-  *x_full_out = c->x_full;
+int hipeig_allgather_block(hipeig_ctx* c, const GatherLayout& gl, int K, const double* xb_local, int64_t n_local,
+                           const double** xb_full_out) {
+  if (!c->collectives) { *xb_full_out = xb_local; return 0; }
+  if (hipeig_block_reserve(c, gl, K)) return 1;
+  for (int k = 0; k < gl.nchunks; ++k) {
+    const int64_t lo = (int64_t)k * gl.h, hi = (lo + gl.h < n_local) ? lo + gl.h : n_local;
+    if (hi > lo) {
+      const int64_t n16 = (hi - lo) * K / 2;
+      hipLaunchKernelGGL(block_rows_copy_kernel, dim3(grid_stream(n16 * 2)), dim3(HIPEIG_BLOCK), 0, c->stream, n16,
+                         reinterpret_cast<const double2*>(xb_local + lo * K),
+                         reinterpret_cast<double2*>(c->xb_full + gl.pos(c->rank, lo) * K));
+    }
+  }
+  HIPEIG_CHECK(hipGetLastError());
+  for (int k = 0; k < gl.nchunks; ++k) {
+    double* region = c->xb_full + gl.cbase[k] * K;
+    if (coll_allgather(c, region + (int64_t)c->rank * gl.cstride(k) * K, region, (size_t)(gl.cstride(k) * K), NCCL_FLOAT64, c->stream)) return 4;
+  }
+  *xb_full_out = c->xb_full;
+  return 0;
+}
+
+// this rank's K-scalar slot inside the block buffer (see hipeig_allgather_block)
+double* hipeig_gather_block_slot(hipeig_ctx* c, const GatherLayout& gl, int K) {
+  if (!c->collectives || !c->xb_full) return nullptr;
+  return c->xb_full + gl.slot(c->rank) * K;
+}
+
+// ---- measurement hooks (bench.py) -------------------------------------------------------------------------------
+// Phase timing of row-partitioned products: on != 0 makes every product record events on both streams.
+extern "C" int hipeig_phase_timing(hipeig_ctx* c, int on) {
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  HIPEIG_CHECK(hipStreamSynchronize(c->comm_stream));
+  c->phase_timing = on ? 1 : 0;
+  return 0;
+}
+
+// Times of the most recent product, in ms (a negative value: that phase did not occur): out[0] the operand exchange
+// (communication stream), [1] sweep of this rank's own windows (under the exchange), [2] sweep of the remaining windows
+// incl. the waits for later chunks, [3] whole product on the compute stream, [4] compute stream idle between the own
+// windows and the first chunk's arrival.
+extern "C" int hipeig_phase_get(hipeig_ctx* c, double out[8]) {
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  HIPEIG_CHECK(hipStreamSynchronize(c->comm_stream));
+  const int pairs[5][2] = {{4, 5}, {0, 1}, {2, 3}, {0, 3}, {1, 2}};
+  for (int k = 0; k < 8; ++k) out[k] = -1.0;
+  for (int k = 0; k < 5; ++k) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev_ph[pairs[k][0]], c->ev_ph[pairs[k][1]]) == hipSuccess) out[k] = ms;
+    else (void)hipGetLastError();
+  }
+  return 0;
+}
+
+// reps SUM all-reduces of `count` doubles back to back on the compute stream; *ms_each = average time of one.
+extern "C" int hipeig_comm_bench_allreduce(hipeig_ctx* c, int count, int reps, double* ms_each) {
+  HIPEIG_REQUIRE(count >= 1 && count <= 1024 && reps >= 1 && ms_each, "bad arguments");
+  double* buf = c->d_scalars + 2048;
+  HIPEIG_CHECK(hipMemsetAsync(buf, 0, (size_t)count * sizeof(double), c->stream));
+  if (hipeig_allreduce_sum(c, buf, count)) return 4;                   // warm-up
+  HIPEIG_CHECK(hipEventRecord(c->ev0, c->stream));
+  for (int k = 0; k < reps; ++k)
+    if (hipeig_allreduce_sum(c, buf, count)) return 4;
+  HIPEIG_CHECK(hipEventRecord(c->ev1, c->stream));
+  HIPEIG_CHECK(hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  HIPEIG_CHECK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *ms_each = ms / reps;
   return 0;
 }

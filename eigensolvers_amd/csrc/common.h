@@ -11,6 +11,29 @@
 #define HIPEIG_BLOCK 256                 // 4 wavefronts per workgroup
 #define HIPEIG_MAX_PARTIALS 2048         // reduction grid cap: 256 CUs x 8 workgroups
 #define HIPEIG_MAX_COLS 16               // basis columns handled per tall-skinny launch
+#define HIPEIG_WIDE_PARTIALS 32768       // grid cap of the reductions that finish in their LAST workgroup (no consumer sums partials)
+#define HIPEIG_GATHER_MAX_CHUNKS 4
+#define HIPEIG_SLOT_DOUBLES 16           // per-rank scalar slot riding on the operand all-gather (one 128-byte line)
+#define HIPEIG_MAX_RANKS 64
+
+// Layout of the all-gathered operand of a row-partitioned operator ("chunk-major"): every rank's row slice is cut
+// into `nchunks` pieces of h rows; chunk c of ALL ranks is contiguous ([chunk][rank][h]), so that one collective per
+// chunk fills one contiguous column range and the sweep of chunk c's column windows can run while chunk c+1 is still
+// travelling.  The last chunk's per-rank stride is h + HIPEIG_SLOT_DOUBLES: the extra line carries a few scalars of
+// the sending rank (MINRES: its share of <y,y>), which therefore reach every rank WITH the operand, no second collective.
+struct GatherLayout {
+  int32_t nranks, nchunks;
+  int64_t h;                                       // rows per (rank, chunk)
+  int64_t cbase[HIPEIG_GATHER_MAX_CHUNKS + 1];     // first position of chunk c; cbase[nchunks] = total length
+  __host__ __device__ int64_t cstride(int c) const { return h + (c == nchunks - 1 ? HIPEIG_SLOT_DOUBLES : 0); }
+  __host__ __device__ int64_t pos(int rank, int64_t i) const {      // local row i of `rank` -> position in the gathered operand
+    int c = (int)(i / h);
+    if (c >= nchunks) c = nchunks - 1;             // never taken for i < nchunks*h; keeps a bad index in range
+    return cbase[c] + (int64_t)rank * cstride(c) + (i - (int64_t)c * h);
+  }
+  __host__ __device__ int64_t slot(int rank) const { return cbase[nchunks - 1] + (int64_t)rank * cstride(nchunks - 1) + h; }
+  __host__ __device__ int64_t total() const { return cbase[nchunks]; }
+};
 
 void hipeig_set_error(const char* fmt, ...);
 
@@ -93,6 +116,15 @@ struct hipeig_ctx {
   int overlap;               // 1: all-gather on the comm stream while the local-column windows are swept
   double* ytmp;              // raw partial sums handed from the local-window launch to the remote one
   int64_t ytmp_n;
+  int gather_chunks;         // chunks the operand all-gather is cut into (HIPEIG_GATHER_CHUNKS; 0 = automatic)
+  hipEvent_t ev_chunk[HIPEIG_GATHER_MAX_CHUNKS];   // chunk c of the current all-gather has arrived (comm stream)
+  unsigned* d_counters;      // arrival counters of the reductions that finish in their last workgroup (zero between kernels)
+  // phase timing of a partitioned product (hipeig_phase_timing): events on both streams
+  int phase_timing;
+  hipEvent_t ev_ph[8];
+  // direct all-gather backend (comm_direct.hip): peers' operand buffers and flags mapped through hipIpc
+  struct DirectComm* direct;
+  int gather_backend;        // 0 = RCCL (or loopback), 1 = direct peer writes
 };
 
 struct hipeig_csr {
@@ -132,23 +164,31 @@ struct hipeig_csr {
   } bl[2];
   int32_t block_variant;     // 0 = automatic, 1 = row-owner CSR, 2 = TCOO-B
   int32_t last_block_variant, last_block_k;
-  int64_t gather_len;        // length of the gathered operand (ncols, or stride*nranks)
+  int64_t gather_len;        // length of the gathered operand (ncols, or gl.total())
+  GatherLayout gl;           // layout of the gathered operand when the columns were remapped (col_stride > 0)
   int variant;               // 0 = auto, 1 = CSR-vector, 2 = CSR-stream, 3 = TCOO (wave units), 4 = TCOO-W, 5 = TCOO-W with fixed-point accumulators
   int last_variant;          // variant used by the most recent launch (0 = none yet)
   int last_launches;         // kernel launches (sweeps) one product with that variant takes
   int lanes_per_row;         // sub-wave width used to reduce one row
-  int64_t col_stride;        // x_full stride per rank when columns were remapped (0 = global)
+  int64_t col_stride;        // > 0 when the columns were remapped to the gathered layout `gl` (= gl.h); 0 = global columns
   int64_t bytes;
 };
 
 // ---- collectives (comm.hip); no-ops without a communicator ---------------------------
-int hipeig_comm_setup_rows(hipeig_ctx* ctx, int64_t nrows_local, int64_t* stride_out);
+int hipeig_comm_setup_rows(hipeig_ctx* ctx, int64_t nrows_local, GatherLayout* gl_out);
 int hipeig_allreduce_sum(hipeig_ctx* ctx, double* d_buf, int count);
-int hipeig_allgather_x(hipeig_ctx* ctx, const double* x_local, int64_t n_local, int64_t stride,
+// whole exchange on the compute stream; *x_full_out = the gathered operand (x_local itself without a communicator)
+int hipeig_allgather_x(hipeig_ctx* ctx, const GatherLayout& gl, const double* x_local, int64_t n_local,
                        const double** x_full_out);
 int hipeig_allgather_f64(hipeig_ctx* ctx, const double* send, double* recv, size_t count);
-int hipeig_allgather_x_begin(hipeig_ctx* ctx, const double* x_local, int64_t n_local, int64_t stride);
-int hipeig_allgather_x_end(hipeig_ctx* ctx, const double** x_full_out);
+// split form: `begin` places this rank's slice in the gathered buffer (compute stream) and starts the exchange chunk by
+// chunk on the communication stream; `wait_chunk` makes the compute stream wait until chunk c of every rank is there.
+int hipeig_allgather_x_begin(hipeig_ctx* ctx, const GatherLayout& gl, const double* x_local, int64_t n_local);
+int hipeig_allgather_x_wait_chunk(hipeig_ctx* ctx, const GatherLayout& gl, int chunk);
+// interleaved block operand of width K (doubles per position): same layout scaled by K, in ctx->xb_full
+int hipeig_allgather_block(hipeig_ctx* ctx, const GatherLayout& gl, int K, const double* xb_local, int64_t n_local,
+                           const double** xb_full_out);
+double* hipeig_gather_slot(hipeig_ctx* ctx, const GatherLayout& gl);     // this rank's scalar slot inside x_full
 
 // ---- device helpers ------------------------------------------------------------------
 // Separately rounded multiply / add.  hipcc contracts a*b+c into an FMA by default and the
@@ -203,6 +243,63 @@ __device__ __forceinline__ double block_sum_partials(const double* __restrict__ 
   for (int w = 1; w < (nt >> 6); ++w) r += lds[w];
   __syncthreads();
   return r;
+}
+
+// ---- reductions that finish in their last workgroup ------------------------------------------------------------
+// Every workgroup stores its partial sum, then takes a ticket; the workgroup holding the last ticket adds ALL partials
+// in fixed order (the tree of block_sum_partials, whichever workgroup happens to be last) and stores the total.  The
+// consumers read one double instead of summing <= 2048 partials in their prologues, so the grid no longer has to be
+// capped at 2048 workgroups: the streaming reductions run on the same n/512-workgroup grids as the element-wise
+// kernels.  `counter` must be zero when the kernel starts and is zero again when it ends.
+// Usage inside a kernel (after every thread that holds a partial has stored it with store_partial):
+//   if (last_block_ticket(counter, tickets)) { t = sum_partials_agent(p, count, lds); if (threadIdx.x == 0) *total = t; ...;
+//                                             release_ticket_counter(counter); }
+__device__ __forceinline__ void store_partial(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// True, uniformly over the workgroup, in the workgroup that takes the last of `tickets` tickets.  The barrier in front
+// makes the partial stores of ALL threads of this workgroup precede thread 0's release.
+__device__ __forceinline__ bool last_block_ticket(unsigned* counter, unsigned tickets) {
+  __shared__ int sh_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    sh_last = (t == tickets - 1u);
+  }
+  __syncthreads();
+  const bool last = sh_last != 0;
+  __syncthreads();                                   // sh_last may be rewritten by the next call
+  return last;
+}
+
+// Fixed-order sum of p[0..count) read past the (per-XCD, mutually incoherent) caches; every thread obtains it.  Same tree
+// as block_sum_partials.
+__device__ __forceinline__ double sum_partials_agent(const double* p, int count, double* lds) {
+  const int nt = blockDim.x < HIPEIG_BLOCK ? (int)blockDim.x : HIPEIG_BLOCK;
+  double a = 0.0;
+  if ((int)threadIdx.x < nt)
+    for (int i = threadIdx.x; i < count; i += nt) a += __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  a = wave_reduce_sum(a);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) lds[wid] = a;
+  __syncthreads();
+  double r = lds[0];
+  for (int w = 1; w < (nt >> 6); ++w) r += lds[w];
+  __syncthreads();
+  return r;
+}
+
+__device__ __forceinline__ void release_ticket_counter(unsigned* counter) {
+  if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Grid of a reduction that finishes in its last workgroup: n/(256*per_thread) workgroups, at most HIPEIG_WIDE_PARTIALS.
+static inline int grid_wide(int64_t n, int per_thread) {
+  int64_t g = (n + (int64_t)HIPEIG_BLOCK * per_thread - 1) / ((int64_t)HIPEIG_BLOCK * per_thread);
+  if (g < 1) g = 1;
+  if (g > HIPEIG_WIDE_PARTIALS) g = HIPEIG_WIDE_PARTIALS;
+  return (int)g;
 }
 
 // Grid of a kernel WITHOUT a reduction (nothing is left per workgroup, so the cap above does not apply): one 16-byte

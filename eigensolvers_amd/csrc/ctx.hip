@@ -31,6 +31,10 @@ extern "C" int hipeig_ctx_create(int device, hipeig_ctx** out) {
   HIPEIG_CHECK(hipEventCreate(&c->ev1));
   HIPEIG_CHECK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
   HIPEIG_CHECK(hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming));
+  for (int k = 0; k < HIPEIG_GATHER_MAX_CHUNKS; ++k) HIPEIG_CHECK(hipEventCreateWithFlags(&c->ev_chunk[k], hipEventDisableTiming));
+  for (int k = 0; k < 8; ++k) HIPEIG_CHECK(hipEventCreate(&c->ev_ph[k]));
+  HIPEIG_CHECK(hipMalloc((void**)&c->d_counters, 64 * sizeof(unsigned)));
+  HIPEIG_CHECK(hipMemset(c->d_counters, 0, 64 * sizeof(unsigned)));
   c->partials_doubles = (size_t)HIPEIG_MAX_PARTIALS * HIPEIG_MAX_COLS * HIPEIG_MAX_COLS * 2;   // 8 MiB
   HIPEIG_CHECK(hipMalloc((void**)&c->d_partials, c->partials_doubles * sizeof(double)));
   c->scalars_doubles = 4096;
@@ -65,7 +69,7 @@ extern "C" int hipeig_ctx_destroy(hipeig_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   hipStreamSynchronize(c->comm_stream);
-  if (c->comm) hipeig_comm_destroy(c);
+  if (c->comm || c->direct) hipeig_comm_destroy(c);
   hipFree(c->d_partials);
   hipFree(c->d_scalars);
   hipHostFree(c->h_scalars);
@@ -88,6 +92,9 @@ extern "C" int hipeig_ctx_destroy(hipeig_ctx* c) {
   hipEventDestroy(c->ev1);
   hipEventDestroy(c->ev_comm);
   hipEventDestroy(c->ev_x);
+  for (int k = 0; k < HIPEIG_GATHER_MAX_CHUNKS; ++k) hipEventDestroy(c->ev_chunk[k]);
+  for (int k = 0; k < 8; ++k) hipEventDestroy(c->ev_ph[k]);
+  hipFree(c->d_counters);
   hipStreamDestroy(c->stream);
   hipStreamDestroy(c->comm_stream);
   free(c);

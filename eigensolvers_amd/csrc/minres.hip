@@ -3,21 +3,25 @@
 // scipy.sparse.linalg.minres, the third-party routine the reference calls at :163).
 //
 // One iteration = three steps, no host round trip:
-//   KA  y = A v - (beta/oldb) r1,  v = r2/beta        (CSR sweep, fused)   + partial <v,y>
-//   KC  y -= (alfa/beta) r2                                              + partial <y,y>
-//   KD  w = (v - oldeps*w1 - delta*w2)/gamma ; x += phi*w                 + partial <x,x>
-// and two kernels on a single GPU: KD(k) is element-wise and needs nothing but beta_{k+1} = sqrt(<y,y>), which KA(k+1)
-// needs as well, so it runs in the row epilogue of KA(k+1)'s sweep (r1 of that sweep IS the r2 that KD(k) reads);
-// the stopping tests of iteration k then sit in KC(k+1)'s prologue, where <x,x> has arrived.  Two global
-// reductions per iteration (alfa, beta) is the least SciPy's recurrences allow.  A chunk of iterations ends with a
-// stand-alone KD + the check kernel, and the next chunk's first KA has nothing pending.  HIPEIG_MINRES_FUSE_KD=0
-// keeps the three-kernel form.
-// The recurrence scalars live in a ring of three MinresState records in device memory: each
-// kernel reads one record and workgroup 0 writes the next, every workgroup having first
-// reduced the previous kernel's <= 2048 partial sums in its prologue (fixed order, so all
-// workgroups obtain the identical value).  The stopping tests of iteration k are evaluated
-// in the prologue of KA(k+1) (or by minres_check_kernel at the end of a chunk); once `done`
-// is set the remaining kernels of the chunk return immediately and x is left untouched.
+//   KA  y = A v - (beta/oldb) r1,  v = r2/beta        (CSR sweep, fused)   + <v,y>
+//   KC  y -= (alfa/beta) r2                                              + <y,y>
+//   KD  w = (v - oldeps*w1 - delta*w2)/gamma ; x += phi*w                 + <x,x>
+// in two kernels: KD(k) is element-wise and needs nothing but beta_{k+1} = sqrt(<y,y>), which KA(k+1) needs as well, so it
+// runs in the row epilogue of KA(k+1)'s sweep (r1 of that sweep IS the r2 that KD(k) reads); the stopping tests of
+// iteration k then sit in KC(k+1)'s prologue, where <x,x> has arrived.  Two global reductions per iteration (alfa, beta)
+// is the least SciPy's recurrences allow.  HIPEIG_MINRES_FUSE_KD=0 keeps the three-kernel form on one GPU.
+//
+// Reductions finish in the LAST workgroup of the kernel that produces them (common.h): consumers read one double, and the
+// element-wise kernels run on uncapped grids.  The recurrence scalars live in a ring of three MinresState records in
+// device memory: each kernel reads one record and workgroup 0 writes the next.  Once `done` is set the remaining kernels
+// of a chunk return immediately and x is left untouched, so x is exactly SciPy's iterate.
+//
+// Row-partitioned run: the SAME two kernels and two collectives per iteration -
+//   * every rank's share of <y,y> rides on the operand all-gather of the next sweep (a scalar slot behind its slice,
+//     GatherLayout::slot), so beta_{k+1}^2 is the directly reduced <y,y> of the updated y, exactly as on one GPU
+//     (round 2 took it as <y,y> - alfa^2 from the un-updated y, which cancels when the right-hand side is close to an
+//     eigenvector - restart vectors, converged Ritz vectors);
+//   * <v,y> and the <x,x> of the KD riding on the sweep share ONE all-reduce of two doubles.
 #include <math.h>
 #include "spmv_device.h"
 
@@ -25,13 +29,14 @@ CsrView hipeig_csr_view(const hipeig_csr* A);
 TcooView hipeig_tcoo_view(const hipeig_csr* A);
 TcooView hipeig_tcoow_view(const hipeig_csr* A);
 size_t hipeig_tcoow_lds_bytes(const hipeig_csr* A);
-int hipeig_tcoow_prepare(hipeig_ctx* c, hipeig_csr* A, const double* x_local, TcooView* tv, const double** xg, int* ncombine);
+int hipeig_tcoow_run_plan(hipeig_ctx* c, hipeig_csr* A, const double* x_local, int fixed, TcooView* last, bool* has_last,
+                          const double** xg, int* ncombine);
 int64_t hipeig_tcoow_part_stride(const hipeig_csr* A);
 int hipeig_tcoow_reserve(hipeig_ctx* c, const hipeig_csr* A);
-int hipeig_fixed_prepare(hipeig_ctx* c, const hipeig_csr* A, const double* xg, TcooView* t);
 int hipeig_spmv_grid(const hipeig_csr* A, int variant);
 int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A);
 size_t hipeig_tcoo_lds_bytes(const hipeig_csr* A);
+void hipeig_phase_mark(hipeig_ctx* c, int k);
 
 #include "minres_device.h"
 
@@ -54,8 +59,7 @@ struct MinresRowEpilogue {
   const double* __restrict__ r2l;   // local slice of r2 (v = s*r2)
   const double* __restrict__ r1;
   double* __restrict__ y;
-  double* yy;                       // fused (distributed) form: running <y,y> of this thread, else null
-  // KD of the previous iteration riding on this sweep (single GPU): r1 is the r2 it reads
+  // KD of the previous iteration riding on this sweep: r1 is the r2 it reads
   int do_kd;
   MinresKd kd;
   const double* __restrict__ w1;
@@ -70,7 +74,6 @@ struct MinresRowEpilogue {
     if (use_r1) yv -= c1 * r1v;
     y[r] = yv;
     acc = fma(v, yv, acc);
-    if (yy) *yy = fma(yv, yv, *yy);
     if (do_kd) {
       double wn, xv = x[r];
       kd.apply(r1v, w1[r], w2[r], wn, xv);
@@ -87,45 +90,37 @@ struct MinresKdArgs {
   const double* w2;
   double* w;
   double* x;
-  double* partials;                 // <x,x> partials, laid out like the launch's <v,y> partials
+  MinresRed red;                    // <x,x>: partials laid out like the launch's <v,y> partials
 };
 
 // VARIANT 1-4: the operator sweep of that layout.  VARIANT 5: the combine step of a split TCOO-W sweep
 // (T.raw_out holds T.part_base slabs of raw sums, see spmv_device.h) - same prologue, same epilogue.
-//
-// FUSED = 1 is the form of a row-partitioned run (one fused, lagged reduction per
-// iteration).  The sweep leaves TWO partial sums per workgroup, <v,y> and <y,y> of the y it has just
-// written, in partials[b] and partials[HIPEIG_MAX_PARTIALS + b]; beta_{k+1}^2 = <y - alfa v, y - alfa v>
-// = <y,y> - alfa^2 then needs no second reduction (v is a unit vector), and the stopping tests of the
-// previous iteration move to the next kernel, where <x,x> arrives with the same all-reduce.
 // FIXED = 1 (VARIANT 4 only): fixed-point accumulators, public kernel variant 5 (spmv_device.h).
-template <int VARIANT, int FUSED = 0, int FIXED = 0>
+// `zero_xx`: a row-partitioned run all-reduces (<v,y>, <x,x>) as one record, so a sweep without a riding KD stores 0 there.
+template <int VARIANT, int FIXED = 0>
 __global__ void __launch_bounds__(VARIANT == 4 ? TCOOW_THREADS : HIPEIG_BLOCK)
 minres_ka_kernel(CsrView A, TcooView T, const double* __restrict__ xg, MinresArgs a, const MinresState* __restrict__ Sin,
                  MinresState* __restrict__ Sout, const double* __restrict__ r2l,
-                 const double* __restrict__ r1, double* __restrict__ y, double* __restrict__ partials,
-                 MinresKdArgs kda = MinresKdArgs{0, nullptr, nullptr, nullptr, nullptr, nullptr}) {
+                 const double* __restrict__ r1, double* __restrict__ y, MinresRed ra, MinresKdArgs kda, int zero_xx) {
   __shared__ double prod[VARIANT == 2 ? SPMV_NNZ_PER_BLOCK : 8];
   __shared__ double red[16];
   extern __shared__ double tcoo_lds[];
   MinresState S = *Sin;
   MinresRowEpilogue epi;
   epi.do_kd = 0;
-  if (!FUSED) {
-    if (kda.do_kd) {
-      // Sin is the record KC left: the scalar half of KD (minres_kd_kernel) happens here, its vector half in the
-      // epilogue; the tests of that iteration wait for its <x,x> (KC's prologue)
-      if (!S.done) {
-        const double bb = sum_or_value(a.pC, a.nC, red);
-        epi.kd.s_old = S.s;
-        minres_advance(S, bb);
-        epi.kd.oldeps = S.oldeps; epi.kd.delta = S.delta; epi.kd.denom = S.denom; epi.kd.phi = S.phi;
-        epi.do_kd = 1;
-      }
-    } else {
-      const double xx = (S.itn > 0 && !S.done) ? sum_or_value(a.pD, a.nD, red) : 0.0;
-      minres_tests(S, xx, a);
+  if (kda.do_kd) {
+    // Sin is the record KC left: the scalar half of KD (minres_kd_kernel) happens here, its vector half in the
+    // epilogue; the tests of that iteration wait for its <x,x> (KC's prologue)
+    if (!S.done) {
+      const double bb = minres_yy(a);
+      epi.kd.s_old = S.s;
+      minres_advance(S, bb);
+      epi.kd.oldeps = S.oldeps; epi.kd.delta = S.delta; epi.kd.denom = S.denom; epi.kd.phi = S.phi;
+      epi.do_kd = 1;
     }
+  } else {
+    const double xx = (S.itn > 0 && !S.done) ? a.pD[0] : 0.0;
+    minres_tests(S, xx, a);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
   if (S.done) return;
@@ -133,99 +128,46 @@ minres_ka_kernel(CsrView A, TcooView T, const double* __restrict__ xg, MinresArg
   epi.use_r1 = S.itn >= 1;
   epi.c1 = epi.use_r1 ? S.beta / S.oldb : 0.0;
   epi.r2l = r2l; epi.r1 = r1; epi.y = y;
-  double acc = 0.0, acc_yy = 0.0, acc_xx = 0.0;
-  epi.yy = FUSED ? &acc_yy : nullptr;
+  double acc = 0.0, acc_xx = 0.0;
   epi.w1 = kda.w1; epi.w2 = kda.w2; epi.w = kda.w; epi.x = kda.x; epi.xx = &acc_xx;
   if (VARIANT == 5) tcoow_combine_sweep(T.raw_out, T.part_base, T.part_stride, T.nrows, epi, acc);
   else if (VARIANT == 4) tcoo_wg_sweep<MinresRowEpilogue, FIXED>(T, xg, epi, acc, tcoo_lds, red);
   else if (VARIANT == 3) tcoo_sweep(T, xg, epi, acc, tcoo_lds);
   else if (VARIANT == 2) csr_stream_sweep(A, xg, epi, acc, prod);
   else csr_vector_sweep(A, xg, epi, acc);
-  if (VARIANT == 4 && T.raw_out) return;                   // raw slabs only: the combine launch owns the partials
   acc = block_reduce_sum(acc, red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc;      // the host offsets `partials` per sweep
-  if (FUSED) {
-    acc_yy = block_reduce_sum(acc_yy, red);
-    if (threadIdx.x == 0) partials[HIPEIG_MAX_PARTIALS + blockIdx.x] = acc_yy;
-  }
-  if (!FUSED && kda.do_kd) {                                 // uniform: every workgroup saw the same record
+  if (threadIdx.x == 0) store_partial(ra.part + blockIdx.x, acc);
+  if (kda.do_kd) {                                           // uniform: every workgroup saw the same record
     acc_xx = block_reduce_sum(acc_xx, red);
-    if (threadIdx.x == 0) kda.partials[blockIdx.x] = acc_xx;
+    if (threadIdx.x == 0) store_partial(kda.red.part + blockIdx.x, acc_xx);
+  }
+  if (last_block_ticket(ra.counter, ra.tickets)) {
+    const double vy = sum_partials_agent(ra.base, ra.count, red);
+    const double xx = kda.do_kd ? sum_partials_agent(kda.red.base, kda.red.count, red) : 0.0;
+    if (threadIdx.x == 0) {
+      *ra.tot = vy;
+      if (kda.do_kd || zero_xx) *kda.red.tot = xx;
+    }
+    release_ticket_counter(ra.counter);
   }
 }
 
-// Fused second half of an iteration of a row-partitioned run: stopping tests of the PREVIOUS iteration
-// (its <x,x> has just arrived), then KC and KD in one pass: y -= (alfa/beta) r2, w, x.  All three sums are
-// all-reduced records of HIPEIG_MAX_PARTIALS slots (unused slots are zero on every rank).
-__global__ void __launch_bounds__(HIPEIG_BLOCK)
-minres_kcd_fused_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, MinresState* __restrict__ Sout,
-                        const double* __restrict__ r2, double* __restrict__ y, const double* __restrict__ w1,
-                        const double* __restrict__ w2, double* __restrict__ w, double* __restrict__ x,
-                        double* __restrict__ partials) {
-  __shared__ double red[4];
-  MinresState S = *Sin;
-  if (!S.done) {
-    const double xx = S.itn > 0 ? block_sum_partials(a.pD, a.nD, red) : 0.0;
-    minres_tests(S, xx, a);
-  }
-  if (S.done) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
-    return;
-  }
-  S.alfa = block_sum_partials(a.pA, a.nA, red);
-  const double yy = block_sum_partials(a.pC, a.nC, red);
-  const double c = S.alfa / S.beta;
-  const double s_old = S.s;
-  minres_advance(S, fmax(yy - S.alfa * S.alfa, 0.0));
-  if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
-  const double oldeps = S.oldeps, delta = S.delta, denom = S.denom, phi = S.phi;
-  const int64_t n2 = n >> 1;
-  const double2* r22 = reinterpret_cast<const double2*>(r2);
-  const double2* w12 = reinterpret_cast<const double2*>(w1);
-  const double2* w22 = reinterpret_cast<const double2*>(w2);
-  double2* y2 = reinterpret_cast<double2*>(y);
-  double2* wn2 = reinterpret_cast<double2*>(w);
-  double2* x2 = reinterpret_cast<double2*>(x);
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-    const double2 rv = r22[i], a1 = w12[i], a2 = w22[i];
-    double2 yv = y2[i], xv = x2[i], wn;
-    yv.x -= c * rv.x; yv.y -= c * rv.y;
-    wn.x = (s_old * rv.x - oldeps * a1.x - delta * a2.x) * denom;
-    wn.y = (s_old * rv.y - oldeps * a1.y - delta * a2.y) * denom;
-    xv.x += phi * wn.x; xv.y += phi * wn.y;
-    y2[i] = yv; wn2[i] = wn; x2[i] = xv;
-    acc = fma(xv.x, xv.x, acc); acc = fma(xv.y, xv.y, acc);
-  }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const int64_t i = n - 1;
-    y[i] -= c * r2[i];
-    const double wn = (s_old * r2[i] - oldeps * w1[i] - delta * w2[i]) * denom;
-    const double xv = x[i] + phi * wn;
-    w[i] = wn; x[i] = xv;
-    acc = fma(xv, xv, acc);
-  }
-  acc = block_reduce_sum(acc, red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
-}
-
+// y -= (alfa/beta) r2 and <y,y>; with test_prev the stopping tests of the previous iteration first (its KD ran in the
+// epilogue of the sweep before this kernel and has left <x,x>).
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
 minres_kc_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, MinresState* __restrict__ Sout,
-                 const double* __restrict__ r2, double* __restrict__ y, double* __restrict__ partials, int test_prev = 0) {
+                 const double* __restrict__ r2, double* __restrict__ y, MinresRed rc, int test_prev) {
   __shared__ double red[4];
   MinresState S = *Sin;
   if (test_prev && !S.done) {
-    // the previous iteration's KD ran in the epilogue of the sweep before this kernel: its stopping tests, with
-    // the <x,x> that sweep has left
-    const double xx = S.itn > 0 ? sum_or_value(a.pD, a.nD, red) : 0.0;
+    const double xx = S.itn > 0 ? a.pD[0] : 0.0;
     minres_tests(S, xx, a);
   }
   if (S.done) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
     return;
   }
-  S.alfa = sum_or_value(a.pA, a.nA, red);
+  S.alfa = a.pA[0];
   if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
   const double c = S.alfa / S.beta;
   const int64_t n2 = n >> 1;
@@ -246,20 +188,28 @@ minres_kc_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, M
     acc = fma(yv, yv, acc);
   }
   acc = block_reduce_sum(acc, red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+  if (threadIdx.x == 0) store_partial(rc.part + blockIdx.x, acc);
+  if (last_block_ticket(rc.counter, rc.tickets)) {
+    const double yy = sum_partials_agent(rc.base, rc.count, red);
+    if (threadIdx.x == 0) {
+      *rc.tot = yy;
+      if (rc.tot2) *rc.tot2 = yy;                            // this rank's share, in the slot that rides on the next operand exchange
+    }
+    release_ticket_counter(rc.counter);
+  }
 }
 
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
 minres_kd_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, MinresState* __restrict__ Sout,
                  const double* __restrict__ r2old, const double* __restrict__ w1, const double* __restrict__ w2,
-                 double* __restrict__ w, double* __restrict__ x, double* __restrict__ partials) {
+                 double* __restrict__ w, double* __restrict__ x, MinresRed rd) {
   __shared__ double red[4];
   MinresState S = *Sin;
   if (S.done) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
     return;
   }
-  const double bb = sum_or_value(a.pC, a.nC, red);
+  const double bb = minres_yy(a);
   const double s_old = S.s;
   minres_advance(S, bb);      // scalar recurrences (every thread, identical)
   if (blockIdx.x == 0 && threadIdx.x == 0) *Sout = S;
@@ -290,14 +240,18 @@ minres_kd_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, M
     acc = fma(xv, xv, acc);
   }
   acc = block_reduce_sum(acc, red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+  if (threadIdx.x == 0) store_partial(rd.part + blockIdx.x, acc);
+  if (last_block_ticket(rd.counter, rd.tickets)) {
+    const double xx = sum_partials_agent(rd.base, rd.count, red);
+    if (threadIdx.x == 0) *rd.tot = xx;
+    release_ticket_counter(rd.counter);
+  }
 }
 
 // End-of-chunk evaluation of the stopping tests (what KA's prologue would do next).
 __global__ void minres_check_kernel(MinresArgs a, MinresState* __restrict__ S0) {
-  __shared__ double red[4];
   MinresState S = *S0;
-  const double xx = (S.itn > 0 && !S.done) ? sum_or_value(a.pD, a.nD, red) : 0.0;
+  const double xx = (S.itn > 0 && !S.done) ? a.pD[0] : 0.0;
   minres_tests(S, xx, a);
   if (threadIdx.x == 0) *S0 = S;
 }
@@ -369,98 +323,102 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
   const CsrView view = hipeig_csr_view(A);
   const TcooView tview = (variant == 4) ? hipeig_tcoow_view(A) : hipeig_tcoo_view(A);
   if (variant == 4) {
-    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<4, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIPEIG_TCOOW_LDS_MAX));
-    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<4, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIPEIG_TCOOW_LDS_MAX));
-    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<4, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIPEIG_TCOOW_LDS_MAX));
-    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<4, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIPEIG_TCOOW_LDS_MAX));
+    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIPEIG_TCOOW_LDS_MAX));
+    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIPEIG_TCOOW_LDS_MAX));
   }
   if (variant == 3)
     HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)HIPEIG_TCOO_LDS_MAX));
   const int gA = hipeig_spmv_grid(A, variant);
-  const int gE = grid_for(n, 4);
+  const int gE = grid_wide(n, 4);                            // element-wise kernels: their reductions finish in the last workgroup
+  // partial-sum areas (HIPEIG_WIDE_PARTIALS apart) and the totals their last workgroups leave
   double* pA = c->d_partials;
-  double* pC = c->d_partials + HIPEIG_MAX_PARTIALS;
-  double* pD = c->d_partials + 2 * HIPEIG_MAX_PARTIALS;
+  double* pC = c->d_partials + HIPEIG_WIDE_PARTIALS;
+  double* pD = c->d_partials + 2 * HIPEIG_WIDE_PARTIALS;
+  double* tot = c->d_scalars + 3072;                         // [0] <v,y>, [1] <x,x> (one all-reduce record), [2] <y,y>, [4..5] end-of-solve flush
+  unsigned* cntA = c->d_counters + 0;
+  unsigned* cntC = c->d_counters + 1;
+  unsigned* cntD = c->d_counters + 2;
   const bool dist = c->collectives != 0;
   MinresArgs a;
   a.sigma = sigma; a.sign = sign; a.rtol = rtol; a.maxiter = maxiter;
   const bool split = (variant == 4) && A->w_csplit > 1;      // raw slabs + combine launch
   const int nsweepA = split ? 1 : (variant == 4) ? (A->w_nunits + gA - 1) / gA
                     : (variant == 3) ? (A->t_nunits + gA * 4 - 1) / (gA * 4) : 1;
-  HIPEIG_REQUIRE(nsweepA * gA <= HIPEIG_MAX_PARTIALS, "too many sweeps for the partial-sum buffer");
+  HIPEIG_REQUIRE(nsweepA * gA <= HIPEIG_WIDE_PARTIALS, "too many sweeps for the partial-sum buffer");
   const int nPA = split ? gE : gA * nsweepA;                 // partial <v,y> sums one iteration leaves in pA
-  // Row-partitioned run: the three partial-sum areas are ONE all-reduce record of 3 x HIPEIG_MAX_PARTIALS
-  // doubles ([<v,y> | <y,y> | <x,x> of the previous iteration], unused slots zero), reduced slot by slot
-  // over the ranks once per iteration; the kernels' prologues then sum the slots in fixed order, so every
-  // rank obtains identical scalars without any reduction launch of its own.
-  double* pE = c->d_partials + 3 * HIPEIG_MAX_PARTIALS;      // copy of the <x,x> area for the end-of-chunk check
-  a.pA = pA; a.nA = dist ? HIPEIG_MAX_PARTIALS : nPA;
-  a.pC = pC; a.nC = dist ? HIPEIG_MAX_PARTIALS : gE;
-  a.pD = pD; a.nD = dist ? HIPEIG_MAX_PARTIALS : gE;
-  if (dist) HIPEIG_CHECK(hipMemsetAsync(pA, 0, (size_t)4 * HIPEIG_MAX_PARTIALS * sizeof(double), c->stream));
+  a.pA = tot + 0; a.nA = 1;
+  a.pD = tot + 1; a.nD = 1;
+  a.pC = tot + 2; a.nC = 1; a.sC = 0;
+  HIPEIG_CHECK(hipMemsetAsync(tot, 0, 8 * sizeof(double), c->stream));
   c->mr_collectives = 0;
+  // Row-partitioned run: <y,y> arrives as one share per rank in the scalar slots of the operand exchange (the pointer
+  // is set per sweep: the direct backend alternates between two buffers)
+  const int64_t slot0 = dist ? A->gl.slot(0) : 0;
+  const int64_t slot_stride = dist ? A->gl.cstride(A->gl.nchunks - 1) : 0;
 
-  // Single GPU: KD(k) rides on the sweep of KA(k+1) (two kernels per iteration, see the header).
+  // KD(k) rides on the sweep of KA(k+1) (two kernels per iteration, see the header); a partitioned run always does.
   const char* fk_env = getenv("HIPEIG_MINRES_FUSE_KD");
-  const bool fuse_kd = !dist && !(fk_env && atoi(fk_env) == 0);
-  MinresArgs a_kc = a;                                       // KC after such a sweep: <x,x> partials laid out like <v,y>
-  a_kc.nD = nPA;
+  const bool fuse_kd = dist || !(fk_env && atoi(fk_env) == 0);
 
-  // The operator sweep of iteration k (all variants); FUSED: also leaves the <y,y> partials.  `kd`: the pending KD of
-  // the previous iteration (do_kd = 0: none), `Sin`: the record the sweep starts from.
-  auto enqueue_ka = [&](int fused, double* r2, double* r1, double* yb, const MinresState* Sin, MinresKdArgs kd) -> int {
+  const MinresRed redC{pC, pC, gE, (unsigned)gE, cntC, tot + 2, nullptr};
+  const MinresRed redD{pD, pD, gE, (unsigned)gE, cntD, tot + 1, nullptr};
+
+  // The operator sweep of iteration k (all variants).  `kd`: the pending KD of the previous iteration (do_kd = 0: none),
+  // `Sin`: the record the sweep starts from.
+  auto enqueue_ka = [&](double* r2, double* r1, double* yb, const MinresState* Sin, MinresKdArgs kd) -> int {
     const double* xg = nullptr;
     TcooView tv = tview;
-#define KA_LAUNCH(VAR, GRID, THREADS, LDS, TV, PARTS, KDP)                                                          \
+    MinresArgs al = a;
+    const int zero_xx = dist ? 1 : 0;
+#define KA_LAUNCH(VAR, FIX, GRID, THREADS, LDS, TV, OFF)                                                            \
     do {                                                                                                            \
       MinresKdArgs kl = kd;                                                                                         \
-      kl.partials = KDP;                                                                                            \
-      if (fused) hipLaunchKernelGGL((minres_ka_kernel<VAR, 1>), dim3(GRID), dim3(THREADS), LDS, c->stream, view, TV, xg, a, Sin, V + 1, r2, r1, yb, PARTS, kl); \
-      else hipLaunchKernelGGL((minres_ka_kernel<VAR, 0>), dim3(GRID), dim3(THREADS), LDS, c->stream, view, TV, xg, a, Sin, V + 1, r2, r1, yb, PARTS, kl);      \
+      kl.red = MinresRed{pD + (OFF), pD, nPA, (unsigned)(split ? gE : nPA), cntD, tot + 1, nullptr};              \
+      const MinresRed ra{pA + (OFF), pA, nPA, (unsigned)(split ? gE : nPA), cntA, tot + 0, nullptr};              \
+      hipLaunchKernelGGL((minres_ka_kernel<VAR, FIX>), dim3(GRID), dim3(THREADS), LDS, c->stream, view, TV, xg, al, Sin, V + 1, r2, r1, yb, ra, kl, zero_xx); \
     } while (0)
     if (variant == 4) {
-      int ncombine = 0;                                           // local windows under the all-gather
-      if (hipeig_tcoow_prepare(c, A, r2, &tv, &xg, &ncombine)) return 4;
-      if (c->collectives) ++c->mr_collectives;                    // the operand all-gather
-      if (fixed && hipeig_fixed_prepare(c, A, xg, &tv)) return 4;
-      for (int sw = 0; sw < nsweepA; ++sw) {
-        tv.unit_begin = sw * gA;
-        if (fixed) {
-          MinresKdArgs kl = kd;
-          kl.partials = pD + sw * gA;
-          if (fused) hipLaunchKernelGGL((minres_ka_kernel<4, 1, 1>), dim3(gA), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, view, tv, xg, a, Sin, V + 1, r2, r1, yb, pA + sw * gA, kl);
-          else hipLaunchKernelGGL((minres_ka_kernel<4, 0, 1>), dim3(gA), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, view, tv, xg, a, Sin, V + 1, r2, r1, yb, pA + sw * gA, kl);
-        } else {
-          KA_LAUNCH(4, gA, TCOOW_THREADS, hipeig_tcoow_lds_bytes(A), tv, pA + sw * gA, pD + sw * gA);
+      bool has_last = true;
+      int ncombine = 0;                                           // own windows under the exchange, chunk by chunk behind it
+      if (hipeig_tcoow_run_plan(c, A, r2, fixed ? 1 : 0, &tv, &has_last, &xg, &ncombine)) return 4;
+      if (dist) { ++c->mr_collectives; al.pC = xg + slot0; al.nC = c->nranks; al.sC = slot_stride; }
+      if (has_last) {
+        for (int sw = 0; sw < nsweepA; ++sw) {
+          tv.unit_begin = sw * gA;
+          if (fixed) KA_LAUNCH(4, 1, gA, TCOOW_THREADS, hipeig_tcoow_lds_bytes(A), tv, sw * gA);
+          else KA_LAUNCH(4, 0, gA, TCOOW_THREADS, hipeig_tcoow_lds_bytes(A), tv, sw * gA);
         }
       }
       if (ncombine) {
         TcooView tc = tv;
+        tc.raw_out = c->ytmp;
         tc.part_base = ncombine;                                  // number of slabs to add
-        KA_LAUNCH(5, gE, HIPEIG_BLOCK, 0, tc, pA, pD);
+        KA_LAUNCH(5, 0, gE, HIPEIG_BLOCK, 0, tc, 0);
       }
+      hipeig_phase_mark(c, 3);
       return 0;
     }
-    if (hipeig_allgather_x(c, r2, n, A->col_stride, &xg)) return 4;
-    if (c->collectives) ++c->mr_collectives;
+    if (hipeig_allgather_x(c, A->gl, r2, n, &xg)) return 4;
+    if (dist) { ++c->mr_collectives; al.pC = xg + slot0; al.nC = c->nranks; al.sC = slot_stride; }
     if (variant == 3) {
       for (int sw = 0; sw < nsweepA; ++sw) {       // one launch per sweep; partials side by side
         tv.unit_begin = sw * gA * 4;
-        KA_LAUNCH(3, gA, HIPEIG_BLOCK, hipeig_tcoo_lds_bytes(A), tv, pA + sw * gA, pD + sw * gA);
+        KA_LAUNCH(3, 0, gA, HIPEIG_BLOCK, hipeig_tcoo_lds_bytes(A), tv, sw * gA);
       }
     } else if (variant == 1) {
-      KA_LAUNCH(1, gA, HIPEIG_BLOCK, 0, tview, pA, pD);
+      KA_LAUNCH(1, 0, gA, HIPEIG_BLOCK, 0, tview, 0);
     } else {
-      KA_LAUNCH(2, gA, HIPEIG_BLOCK, 0, tview, pA, pD);
+      KA_LAUNCH(2, 0, gA, HIPEIG_BLOCK, 0, tview, 0);
     }
 #undef KA_LAUNCH
     return 0;
   };
 
-  const MinresKdArgs no_kd{0, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const MinresKdArgs no_kd{0, nullptr, nullptr, nullptr, nullptr, MinresRed{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr}};
   // One iteration's launches on the compute stream (buffer roles rotate with period 3).  `first`: nothing is pending
-  // from the iteration before (the first iteration of a chunk: the chunk before ended with a stand-alone KD).
+  // from the iteration before (one GPU: the first iteration of a chunk - the chunk before ended with a stand-alone KD;
+  // partitioned run: only the very first iteration, the pending KD is carried over the chunk boundary).
   auto enqueue_iteration = [&](int k, bool first) -> int {
     double* r2 = R[k % 3];
     double* yb = R[(k + 1) % 3];
@@ -468,31 +426,36 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
     double* wn = W[k % 3];
     double* w1 = W[(k + 1) % 3];
     double* w2 = W[(k + 2) % 3];
-    if (dist) {
-      // all-gather + sweep, ONE all-reduce, fused update: 2 collectives and 2 (+ sweeps) launches
-      if (enqueue_ka(1, r2, r1, yb, V + 0, no_kd)) return 4;
-      if (hipeig_allreduce_sum(c, pA, 3 * HIPEIG_MAX_PARTIALS)) return 4;
-      ++c->mr_collectives;
-      hipLaunchKernelGGL(minres_kcd_fused_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 1, V + 0, r2, yb, w1, w2, wn, xw, pD);
-      return 0;
-    }
     if (fuse_kd) {
       // KD(k-1): w = W[(k-1)%3] from w1 = W[k%3], w2 = W[(k+1)%3] and r2 of that iteration = this one's r1
       const bool pending = !first;
-      const MinresKdArgs kd{pending ? 1 : 0, wn, w1, w2, xw, nullptr};
-      if (enqueue_ka(0, r2, r1, yb, pending ? V + 2 : V + 0, kd)) return 4;
-      hipLaunchKernelGGL(minres_kc_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, pending ? a_kc : a, V + 1, V + 2, r2, yb, pC, pending ? 1 : 0);
+      MinresKdArgs kd = no_kd;
+      kd.do_kd = pending ? 1 : 0; kd.w1 = wn; kd.w2 = w1; kd.w = w2; kd.x = xw;
+      if (enqueue_ka(r2, r1, yb, pending ? V + 2 : V + 0, kd)) return 4;
+      if (dist) {                                                // (<v,y>, <x,x>) in one all-reduce
+        if (hipeig_allreduce_sum(c, tot, 2)) return 4;
+        ++c->mr_collectives;
+      }
+      MinresRed rc = redC;
+      if (dist) rc.tot2 = hipeig_gather_slot(c, A->gl);          // travels with the NEXT exchange
+      hipLaunchKernelGGL(minres_kc_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 1, V + 2, r2, yb, rc, pending ? 1 : 0);
       return 0;
     }
-    if (enqueue_ka(0, r2, r1, yb, V + 0, no_kd)) return 4;
-    hipLaunchKernelGGL(minres_kc_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 1, V + 2, r2, yb, pC, 0);
-    hipLaunchKernelGGL(minres_kd_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 2, V + 0, r2, w1, w2, wn, xw, pD);
+    if (enqueue_ka(r2, r1, yb, V + 0, no_kd)) return 4;
+    hipLaunchKernelGGL(minres_kc_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 1, V + 2, r2, yb, redC, 0);
+    hipLaunchKernelGGL(minres_kd_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 2, V + 0, r2, w1, w2, wn, xw, redD);
     return 0;
   };
-  // The KD of a chunk's last iteration k (nothing follows it inside the chunk to ride on).
+  // The KD of iteration k as its own kernel (nothing follows to ride on): the end of a chunk on one GPU, the end of the
+  // solve on a partitioned run (whose <y,y> shares have not travelled: one extra all-reduce).
   auto enqueue_last_kd = [&](int k) -> int {
     if (!fuse_kd) return 0;
-    hipLaunchKernelGGL(minres_kd_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 2, V + 0, R[k % 3], W[(k + 1) % 3], W[(k + 2) % 3], W[k % 3], xw, pD);
+    MinresArgs al = a;
+    if (dist) {
+      if (hipeig_allreduce_sum(c, tot + 2, 1)) return 4;
+      ++c->mr_collectives;
+    }
+    hipLaunchKernelGGL(minres_kd_kernel, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, al, V + 2, V + 0, R[k % 3], W[(k + 1) % 3], W[(k + 2) % 3], W[k % 3], xw, redD);
     return 0;
   };
   // diagnostic knobs for the rocprofv3-inside-capture question (profiles/r02_hipgraph_under_rocprofv3.txt):
@@ -506,16 +469,11 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
   const bool gtrace = getenv("HIPEIG_GRAPH_TRACE") != nullptr;       // stderr markers around the graph API calls
 #define GTRACE(msg) do { if (gtrace) { fprintf(stderr, "[hipeig graph] %s\n", msg); fflush(stderr); } } while (0)
   auto enqueue_check = [&]() -> int {
-    MinresArgs ac = a;
     if (dist) {
-      // the last iteration's <x,x> has not been through an all-reduce yet; reduce a COPY, the area itself
-      // is reduced (once) with the next iteration's record
-      HIPEIG_CHECK(hipMemcpyAsync(pE, pD, (size_t)HIPEIG_MAX_PARTIALS * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-      if (hipeig_allreduce_sum(c, pE, HIPEIG_MAX_PARTIALS)) return 4;
+      if (hipeig_allreduce_sum(c, tot + 1, 1)) return 4;      // the stand-alone KD's <x,x>
       ++c->mr_collectives;
-      ac.pD = pE;
     }
-    hipLaunchKernelGGL(minres_check_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, ac, V + 0);
+    hipLaunchKernelGGL(minres_check_kernel, dim3(1), dim3(64), 0, c->stream, a, V + 0);
     if (!capturing || graph_copy_node)
       HIPEIG_CHECK(hipMemcpyAsync(h, V, sizeof(MinresState), hipMemcpyDeviceToHost, c->stream));
     return 0;
@@ -577,19 +535,27 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
   } else {
     // iterations between two looks at the state record (check kernel + copy-back + host sync: ~70 us at N = 1e6, where
     // an iteration takes 140 us).  Kernels launched past the stopping iteration return at once (~5 us each), so a longer
-    // chunk wastes at most that; a partitioned run keeps 16 (its check costs a collective on every rank).
+    // chunk wastes at most that.  One GPU: a chunk ends with the stand-alone KD and the check kernel.  Partitioned run:
+    // no flush at a chunk boundary (it would cost two extra collectives) - the host looks at the record KC left, which
+    // holds the tests of the iteration before, and the pending KD is carried into the next chunk; only when the
+    // iteration limit is reached are the last KD and the last tests run on their own.
     const int chunk = dist ? 16 : 32;
     int k = 0;
     while (k < maxiter) {
       const int kend = (k + chunk < maxiter) ? k + chunk : maxiter;
       const int kfirst = k;
       for (; k < kend; ++k) {
-        const int rc = enqueue_iteration(k, k == kfirst);
+        const int rc = enqueue_iteration(k, dist ? (k == 0) : (k == kfirst));
         if (rc) return rc;
       }
-      if (enqueue_last_kd(kend - 1)) return 1;
       HIPEIG_CHECK(hipGetLastError());
-      if (enqueue_check()) return 1;
+      if (dist && kend < maxiter) {
+        HIPEIG_CHECK(hipMemcpyAsync(h, V + 2, sizeof(MinresState), hipMemcpyDeviceToHost, c->stream));
+      } else {
+        if (enqueue_last_kd(kend - 1)) return 1;
+        HIPEIG_CHECK(hipGetLastError());
+        if (enqueue_check()) return 1;
+      }
       HIPEIG_CHECK(hipStreamSynchronize(c->stream));
       if (h->done) break;
     }

@@ -23,6 +23,8 @@ int hipeig_block_allgather(hipeig_ctx* c, hipeig_csr* A, int K, const double* xb
 int hipeig_block_pack(hipeig_ctx* c, int K, int64_t n, int k, const double* const* cols, double* blk);
 int hipeig_block_unpack(hipeig_ctx* c, int K, int64_t n, int k, const double* blk, double* const* cols);
 int hipeig_rowowner_grid(const hipeig_ctx* c, const hipeig_csr* A);
+double* hipeig_gather_block_slot(hipeig_ctx* c, const GatherLayout& gl, int K);
+int hipeig_block_reserve(hipeig_ctx* c, const GatherLayout& gl, int K);
 
 #define MRB_PART_STRIDE (HIPEIG_MAX_PARTIALS * BCOO_KMAX)     // doubles between the three partial areas
 
@@ -41,7 +43,6 @@ struct MinresBlockEpilogue {
   const double* __restrict__ r2l;    // local rows of R2 (v = s*r2)
   const double* __restrict__ r1;
   double* __restrict__ y;
-  double* yy;                        // fused (row-partitioned) form: running <y_j, y_j> of this thread, else null
   __device__ __forceinline__ void elem(int64_t r, int j, double sum, double& acc) const {
     const int64_t i = r * K + j;
     const double v = s * r2l[i];
@@ -49,15 +50,13 @@ struct MinresBlockEpilogue {
     if (use_r1) yv -= c1 * r1[i];
     y[i] = yv;
     acc = fma(v, yv, acc);
-    if (yy) *yy = fma(yv, yv, *yy);
   }
 };
 
 // VARIANT 2: window-blocked (TCOO-B) sweep, 1024 threads; VARIANT 1: row-owner CSR sweep, 256 threads.
-// FUSED = 1: the form of a row-partitioned run, as in minres.hip - the sweep also leaves the partials of
-// <y_j, y_j> (one area further, at partials + MRB_PART_STRIDE) so that beta^2 = <y,y> - alfa^2 needs no second
-// reduction, and the stopping tests move to the fused update kernel, where the lagged <x,x> arrives.
-template <int VARIANT, int K, int FUSED = 0>
+// LATE_TESTS = 1: the form of a row-partitioned run - the stopping tests of the previous iteration are not evaluated
+// here but in KC's prologue, where its <x,x> arrives with the all-reduce that also carries this sweep's <v,y>.
+template <int VARIANT, int K, int LATE_TESTS = 0>
 __global__ void __launch_bounds__(VARIANT == 2 ? BCOO_THREADS : HIPEIG_BLOCK)
 minres_block_ka_kernel(BcooView T, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                        const double* __restrict__ val, int64_t nrows, const double* __restrict__ xg, MinresArgs a,
@@ -68,12 +67,12 @@ minres_block_ka_kernel(BcooView T, const int32_t* __restrict__ rowptr, const int
   __shared__ double sh_s[K], sh_c1[K];
   __shared__ int sh_use[K], sh_live;
   extern __shared__ double bcoo_lds[];
-  const double xx = FUSED ? 0.0 : sum_or_value_cols<K>(a.pD, a.nD, red);
+  const double xx = LATE_TESTS ? 0.0 : sum_or_value_cols<K>(a.pD, a.nD, red);
   if (threadIdx.x == 0) sh_live = 0;
   __syncthreads();
   if (threadIdx.x < K) {
     MinresState S = Sin[threadIdx.x];
-    if (!FUSED) minres_tests(S, (S.itn > 0 && !S.done) ? xx : 0.0, a);
+    if (!LATE_TESTS) minres_tests(S, (S.itn > 0 && !S.done) ? xx : 0.0, a);
     if (blockIdx.x == 0) Sout[threadIdx.x] = S;
     const int use = (!S.done && S.itn >= 1);
     sh_s[threadIdx.x] = S.done ? 0.0 : S.s;
@@ -87,16 +86,11 @@ minres_block_ka_kernel(BcooView T, const int32_t* __restrict__ rowptr, const int
   const int j = threadIdx.x % K;
   epi.sigma = a.sigma; epi.sign = a.sign; epi.s = sh_s[j]; epi.c1 = sh_c1[j]; epi.use_r1 = sh_use[j];
   epi.r2l = r2l; epi.r1 = r1; epi.y = y;
-  double acc = 0.0, acc_yy = 0.0;
-  epi.yy = FUSED ? &acc_yy : nullptr;
+  double acc = 0.0;
   if (VARIANT == 2) bcoo_wg_sweep<K>(T, xg, epi, acc, bcoo_lds);
   else csr_rowowner_block_sweep<K>(rowptr, col, val, nrows, xg, epi, acc);
   const double tot = block_reduce_cols<K>(acc, red);
   if (threadIdx.x < K) partials[(size_t)blockIdx.x * K + threadIdx.x] = tot;
-  if (FUSED) {
-    const double tyy = block_reduce_cols<K>(acc_yy, red);
-    if (threadIdx.x < K) partials[MRB_PART_STRIDE + (size_t)blockIdx.x * K + threadIdx.x] = tyy;
-  }
 }
 
 // Fold (a0, a1) - partials of operands 2(t % (K/2)) and the next - over the workgroup; record in threads 0..K-1.
@@ -120,12 +114,14 @@ __device__ __forceinline__ void block_reduce_pairs(double a0, double a1, double*
 template <int K>
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
 minres_block_kc_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, MinresState* __restrict__ Sout,
-                       const double* __restrict__ r2, double* __restrict__ y, double* __restrict__ partials) {
+                       const double* __restrict__ r2, double* __restrict__ y, double* __restrict__ partials, int test_prev) {
   __shared__ double red[HIPEIG_BLOCK / 64 * K];
   __shared__ double sh_c[K];
   const double alfa = sum_or_value_cols<K>(a.pA, a.nA, red);
+  const double xx = test_prev ? sum_or_value_cols<K>(a.pD, a.nD, red) : 0.0;
   if (threadIdx.x < K) {
     MinresState S = Sin[threadIdx.x];
+    if (test_prev) minres_tests(S, (S.itn > 0 && !S.done) ? xx : 0.0, a);      // row-partitioned run: the tests of the iteration before
     if (!S.done) S.alfa = alfa;
     if (blockIdx.x == 0) Sout[threadIdx.x] = S;
     sh_c[threadIdx.x] = S.done ? 0.0 : S.alfa / S.beta;
@@ -156,7 +152,14 @@ minres_block_kd_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ 
   __shared__ double red[HIPEIG_BLOCK / 64 * K];
   __shared__ double sh_sold[K], sh_oldeps[K], sh_delta[K], sh_denom[K], sh_phi[K];
   __shared__ int sh_done[K];
-  const double bb = sum_or_value_cols<K>(a.pC, a.nC, red);
+  double bb;
+  if (a.sC > 0) {                                       // one share of <y_j,y_j> per rank, in the slots of the operand exchange
+    bb = 0.0;
+    if (threadIdx.x < K)
+      for (int r = 0; r < a.nC; ++r) bb += a.pC[(int64_t)r * a.sC + threadIdx.x];
+  } else {
+    bb = sum_or_value_cols<K>(a.pC, a.nC, red);
+  }
   if (threadIdx.x < K) {
     MinresState S = Sin[threadIdx.x];
     sh_sold[threadIdx.x] = S.s;
@@ -196,71 +199,14 @@ minres_block_kd_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ 
   block_reduce_pairs<K>(a0, a1, red, partials + (size_t)blockIdx.x * K);
 }
 
-// Fused second half of an iteration of a row-partitioned run (the block form of minres_kcd_fused_kernel):
-// per column the stopping tests of the PREVIOUS iteration (its <x,x> has just arrived with the all-reduce),
-// then KC and KD in one pass.  a.pA / a.pC / a.pD point at the three all-reduced records of K sums.
+// Row-partitioned run: this rank's two records (<v,y> of the sweep, <x,x> of the KD before it) of K sums each, at
+// out + 0 / 8, from the partial areas - ONE all-reduce of 16 doubles follows.  One workgroup per record.
 template <int K>
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
-minres_block_kcd_fused_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, MinresState* __restrict__ Sout,
-                              const double* __restrict__ r2, double* __restrict__ y, const double* __restrict__ w1,
-                              const double* __restrict__ w2, double* __restrict__ w, double* __restrict__ x,
-                              double* __restrict__ partials) {
+sum_two_records_kernel(const double* __restrict__ pA, int nA, const double* __restrict__ pD, int nD, double* __restrict__ out) {
   __shared__ double red[HIPEIG_BLOCK / 64 * K];
-  __shared__ double sh_c[K], sh_sold[K], sh_oldeps[K], sh_delta[K], sh_denom[K], sh_phi[K];
-  __shared__ int sh_done[K];
-  if (threadIdx.x < K) {
-    MinresState S = Sin[threadIdx.x];
-    if (!S.done) minres_tests(S, S.itn > 0 ? a.pD[threadIdx.x] : 0.0, a);
-    sh_sold[threadIdx.x] = S.s;
-    double c = 0.0;
-    if (!S.done) {
-      S.alfa = a.pA[threadIdx.x];
-      c = S.alfa / S.beta;
-      minres_advance(S, fmax(a.pC[threadIdx.x] - S.alfa * S.alfa, 0.0));
-    }
-    if (blockIdx.x == 0) Sout[threadIdx.x] = S;
-    sh_c[threadIdx.x] = c;
-    sh_oldeps[threadIdx.x] = S.oldeps; sh_delta[threadIdx.x] = S.delta;
-    sh_denom[threadIdx.x] = S.denom; sh_phi[threadIdx.x] = S.phi;
-    sh_done[threadIdx.x] = S.done;
-  }
-  __syncthreads();
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int j0 = (int)(t0 % (K / 2)) * 2, j1 = j0 + 1;
-  const double c0 = sh_c[j0], s0 = sh_sold[j0], e0 = sh_oldeps[j0], d0 = sh_delta[j0], q0 = sh_denom[j0], p0 = sh_phi[j0];
-  const double c1 = sh_c[j1], s1 = sh_sold[j1], e1 = sh_oldeps[j1], d1 = sh_delta[j1], q1 = sh_denom[j1], p1 = sh_phi[j1];
-  const bool live0 = !sh_done[j0], live1 = !sh_done[j1];
-  const double2* r22 = reinterpret_cast<const double2*>(r2);
-  const double2* w12 = reinterpret_cast<const double2*>(w1);
-  const double2* w22 = reinterpret_cast<const double2*>(w2);
-  double2* y2 = reinterpret_cast<double2*>(y);
-  double2* wn2 = reinterpret_cast<double2*>(w);
-  double2* x2 = reinterpret_cast<double2*>(x);
-  double a0 = 0.0, a1 = 0.0;
-  for (int64_t t = t0; t < n * (K / 2); t += stride) {
-    const double2 rv = r22[t], b1 = w12[t], b2 = w22[t];
-    double2 yv = y2[t], xv = x2[t], wn;
-    yv.x -= c0 * rv.x; yv.y -= c1 * rv.y;
-    wn.x = (s0 * rv.x - e0 * b1.x - d0 * b2.x) * q0;
-    wn.y = (s1 * rv.y - e1 * b1.y - d1 * b2.y) * q1;
-    if (live0) xv.x += p0 * wn.x;                        // a stopped column keeps its iterate
-    if (live1) xv.y += p1 * wn.y;
-    y2[t] = yv; wn2[t] = wn; x2[t] = xv;
-    a0 = fma(xv.x, xv.x, a0); a1 = fma(xv.y, xv.y, a1);
-  }
-  block_reduce_pairs<K>(a0, a1, red, partials + (size_t)blockIdx.x * K);
-}
-
-// Row-partitioned run: this rank's three records (<v,y>, <y,y>, lagged <x,x>) of K sums each, at out + 0 / 8 / 16,
-// from the three partial areas - ONE all-reduce of 24 doubles follows.  One workgroup per record.
-template <int K>
-__global__ void __launch_bounds__(HIPEIG_BLOCK)
-sum_three_records_kernel(const double* __restrict__ pA, int nA, const double* __restrict__ pC, int nC,
-                         const double* __restrict__ pD, int nD, double* __restrict__ out) {
-  __shared__ double red[HIPEIG_BLOCK / 64 * K];
-  const double* p = blockIdx.x == 0 ? pA : blockIdx.x == 1 ? pC : pD;
-  const int cnt = blockIdx.x == 0 ? nA : blockIdx.x == 1 ? nC : nD;
+  const double* p = blockIdx.x == 0 ? pA : pD;
+  const int cnt = blockIdx.x == 0 ? nA : nD;
   const double v = block_sum_partials_cols<K>(p, cnt, red);
   if (threadIdx.x < K) out[blockIdx.x * 8 + threadIdx.x] = v;
 }
@@ -357,61 +303,78 @@ static int minres_block_impl(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   double* pD = c->d_partials + 2 * MRB_PART_STRIDE;
   HIPEIG_REQUIRE(c->partials_doubles >= (size_t)3 * MRB_PART_STRIDE, "partial-sum workspace too small");
   const bool dist = c->collectives != 0;
-  double* red = c->d_scalars + 2048;                  // row-partitioned run: three reduced records of 8 (+ one for the chunk check)
+  // row-partitioned run: reduced records of 8 - [0..7] <v,y>, [8..15] <x,x> (ONE all-reduce), [16..23] / [24..31] the
+  // end-of-solve flush
+  double* red = c->d_scalars + 2048;
   MinresArgs a;
-  a.sigma = sigma; a.sign = sign; a.rtol = rtol; a.maxiter = maxiter;
+  a.sigma = sigma; a.sign = sign; a.rtol = rtol; a.maxiter = maxiter; a.sC = 0;
   const int nPA = gA * nsweepA;
   a.pA = dist ? red + 0 : pA; a.nA = dist ? 1 : nPA;
-  a.pC = dist ? red + 8 : pC; a.nC = dist ? 1 : gE;
-  a.pD = dist ? red + 16 : pD; a.nD = dist ? 1 : gE;
+  a.pC = pC; a.nC = gE;
+  a.pD = dist ? red + 8 : pD; a.nD = dist ? 1 : gE;
+  double* slot = nullptr;
+  MinresArgs a_kd = a;                                  // KD of a partitioned run: <y_j,y_j> as one share per rank from the exchange's slots
   if (dist) {
     HIPEIG_CHECK(hipMemsetAsync(red, 0, 32 * sizeof(double), c->stream));
-    HIPEIG_CHECK(hipMemsetAsync(pD, 0, (size_t)gE * K * sizeof(double), c->stream));     // the lagged <x,x> of "iteration -1"
+    if (hipeig_block_reserve(c, A->gl, K)) return 1;
+    slot = hipeig_gather_block_slot(c, A->gl, K);
+    HIPEIG_REQUIRE(slot != nullptr, "no block exchange buffer");
+    a_kd.pC = c->xb_full + A->gl.slot(0) * K; a_kd.nC = c->nranks; a_kd.sC = A->gl.cstride(A->gl.nchunks - 1) * K;
   }
   c->mr_collectives = 0;
+
+  auto launch_ka = [&](const double* xg, double* r2, double* r1, double* yb, bool late) {
+    if (bv == 2) {
+      BcooView tv = tview;
+      for (int sw = 0; sw < nsweepA; ++sw) {
+        tv.unit_begin = sw * gA;
+        if (late) hipLaunchKernelGGL((minres_block_ka_kernel<2, K, 1>), dim3(gA), dim3(BCOO_THREADS), hipeig_bcoo_lds_bytes(A, K), c->stream,
+                                     tv, A->d_rowptr, A->d_col, A->d_val, n, xg, a, V + 0, V + 8, r2, r1, yb, pA + (size_t)sw * gA * K);
+        else hipLaunchKernelGGL((minres_block_ka_kernel<2, K>), dim3(gA), dim3(BCOO_THREADS), hipeig_bcoo_lds_bytes(A, K), c->stream,
+                                tv, A->d_rowptr, A->d_col, A->d_val, n, xg, a, V + 0, V + 8, r2, r1, yb, pA + (size_t)sw * gA * K);
+      }
+    } else if (late) {
+      hipLaunchKernelGGL((minres_block_ka_kernel<1, K, 1>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream,
+                         tview, A->d_rowptr, A->d_col, A->d_val, n, xg, a, V + 0, V + 8, r2, r1, yb, pA);
+    } else {
+      hipLaunchKernelGGL((minres_block_ka_kernel<1, K>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream,
+                         tview, A->d_rowptr, A->d_col, A->d_val, n, xg, a, V + 0, V + 8, r2, r1, yb, pA);
+    }
+  };
+  // KD of iteration `it` (buffers of that iteration)
+  auto launch_kd = [&](int it, const MinresArgs& ak) {
+    hipLaunchKernelGGL(minres_block_kd_kernel<K>, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, ak, V + 16, V + 0,
+                       R[it % 3], W[(it + 1) % 3], W[(it + 2) % 3], W[it % 3], xw, pD);
+  };
+
+  if (bv == 2)
+    HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_block_ka_kernel<2, K, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)HIPEIG_BCOO_LDS_MAX));
 
   auto enqueue_iteration = [&](int it) -> int {
     double* r2 = R[it % 3];
     double* yb = R[(it + 1) % 3];
     double* r1 = R[(it + 2) % 3];
-    double* wn = W[it % 3];
-    double* w1 = W[(it + 1) % 3];
-    double* w2 = W[(it + 2) % 3];
     const double* xg = nullptr;
     if (hipeig_block_allgather(c, A, K, r2, &xg)) return 4;
     if (dist) {
-      // all-gather + sweep, ONE all-reduce of the three records, fused update: 2 collectives per iteration
+      // Two collectives per iteration, as for one right-hand side (minres.hip): the exchange of the operand block carries
+      // every rank's shares of <y_j,y_j> (so beta is the directly reduced norm of the updated y, not <y,y> - alfa^2), and
+      // one all-reduce carries <v_j,y_j> together with the <x_j,x_j> of the KD that ran just before the sweep.
       ++c->mr_collectives;
-      if (bv == 2) {
-        BcooView tv = tview;
-        for (int sw = 0; sw < nsweepA; ++sw) {
-          tv.unit_begin = sw * gA;
-          hipLaunchKernelGGL((minres_block_ka_kernel<2, K, 1>), dim3(gA), dim3(BCOO_THREADS), hipeig_bcoo_lds_bytes(A, K), c->stream,
-                             tv, A->d_rowptr, A->d_col, A->d_val, n, xg, a, V + 0, V + 8, r2, r1, yb, pA + (size_t)sw * gA * K);
-        }
-      } else {
-        hipLaunchKernelGGL((minres_block_ka_kernel<1, K, 1>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream,
-                           tview, A->d_rowptr, A->d_col, A->d_val, n, xg, a, V + 0, V + 8, r2, r1, yb, pA);
-      }
-      hipLaunchKernelGGL(sum_three_records_kernel<K>, dim3(3), dim3(HIPEIG_BLOCK), 0, c->stream, pA, nPA, pC, nPA, pD, gE, red);
-      if (hipeig_allreduce_sum(c, red, 24)) return 4;
+      if (it > 0) launch_kd(it - 1, a_kd);
+      else HIPEIG_CHECK(hipMemsetAsync(pD, 0, (size_t)gE * K * sizeof(double), c->stream));
+      launch_ka(xg, r2, r1, yb, true);
+      hipLaunchKernelGGL(sum_two_records_kernel<K>, dim3(2), dim3(HIPEIG_BLOCK), 0, c->stream, pA, nPA, pD, gE, red);
+      if (hipeig_allreduce_sum(c, red, 16)) return 4;
       ++c->mr_collectives;
-      hipLaunchKernelGGL(minres_block_kcd_fused_kernel<K>, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 8, V + 0, r2, yb, w1, w2, wn, xw, pD);
+      hipLaunchKernelGGL(minres_block_kc_kernel<K>, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 8, V + 16, r2, yb, pC, it > 0 ? 1 : 0);
+      hipLaunchKernelGGL(sum_partials_cols_kernel<K>, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pC, gE, slot);   // travels with the next exchange
       return 0;
     }
-    if (bv == 2) {
-      BcooView tv = tview;
-      for (int sw = 0; sw < nsweepA; ++sw) {
-        tv.unit_begin = sw * gA;
-        hipLaunchKernelGGL((minres_block_ka_kernel<2, K>), dim3(gA), dim3(BCOO_THREADS), hipeig_bcoo_lds_bytes(A, K), c->stream,
-                           tv, A->d_rowptr, A->d_col, A->d_val, n, xg, a, V + 0, V + 8, r2, r1, yb, pA + (size_t)sw * gA * K);
-      }
-    } else {
-      hipLaunchKernelGGL((minres_block_ka_kernel<1, K>), dim3(gA), dim3(HIPEIG_BLOCK), 0, c->stream,
-                         tview, A->d_rowptr, A->d_col, A->d_val, n, xg, a, V + 0, V + 8, r2, r1, yb, pA);
-    }
-    hipLaunchKernelGGL(minres_block_kc_kernel<K>, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 8, V + 16, r2, yb, pC);
-    hipLaunchKernelGGL(minres_block_kd_kernel<K>, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 16, V + 0, r2, w1, w2, wn, xw, pD);
+    launch_ka(xg, r2, r1, yb, false);
+    hipLaunchKernelGGL(minres_block_kc_kernel<K>, dim3(gE), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, V + 8, V + 16, r2, yb, pC, 0);
+    launch_kd(it, a);
     return 0;
   };
 
@@ -425,17 +388,28 @@ static int minres_block_impl(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
       if (rc) return rc;
     }
     HIPEIG_CHECK(hipGetLastError());
-    MinresArgs ac = a;
-    if (dist) {
-      // the last iteration's <x,x> has not been through an all-reduce yet: reduce a separate record for the
-      // check; the partial area itself joins the next iteration's record
-      hipLaunchKernelGGL(sum_partials_cols_kernel<K>, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pD, gE, red + 24);
-      if (hipeig_allreduce_sum(c, red + 24, K)) return 4;
-      ++c->mr_collectives;
-      ac.pD = red + 24;
+    if (dist && iend < maxiter) {
+      // no flush at a chunk boundary: the records KC left hold the tests of the iteration before; the pending KD runs at
+      // the start of the next chunk
+      HIPEIG_CHECK(hipMemcpyAsync(h, V + 16, K * sizeof(MinresState), hipMemcpyDeviceToHost, c->stream));
+    } else {
+      MinresArgs ac = a;
+      if (dist) {
+        // end of the solve: the last KD and the last tests on their own (their sums have not travelled: two small all-reduces)
+        HIPEIG_CHECK(hipMemcpyAsync(red + 16, slot, K * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        if (hipeig_allreduce_sum(c, red + 16, K)) return 4;
+        ++c->mr_collectives;
+        MinresArgs ak = a;
+        ak.pC = red + 16; ak.nC = 1; ak.sC = 0;
+        launch_kd(iend - 1, ak);
+        hipLaunchKernelGGL(sum_partials_cols_kernel<K>, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, pD, gE, red + 24);
+        if (hipeig_allreduce_sum(c, red + 24, K)) return 4;
+        ++c->mr_collectives;
+        ac.pD = red + 24;
+      }
+      hipLaunchKernelGGL(minres_block_check_kernel<K>, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, ac, V + 0);
+      HIPEIG_CHECK(hipMemcpyAsync(h, V, K * sizeof(MinresState), hipMemcpyDeviceToHost, c->stream));
     }
-    hipLaunchKernelGGL(minres_block_check_kernel<K>, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, ac, V + 0);
-    HIPEIG_CHECK(hipMemcpyAsync(h, V, K * sizeof(MinresState), hipMemcpyDeviceToHost, c->stream));
     HIPEIG_CHECK(hipStreamSynchronize(c->stream));
     all_done = true;
     for (int j = 0; j < K; ++j) all_done = all_done && h[j].done;

@@ -10,13 +10,35 @@
 struct MinresArgs {
   double sigma, sign, rtol;
   int maxiter;
-  int nA, nC, nD;                 // number of valid partials of KA / KC / KD (1 = already reduced)
+  int nA, nC, nD;                 // number of values behind pA / pC / pD that add up to <v,y> / <y,y> / <x,x> (1 = the sum itself)
   const double* pA; const double* pC; const double* pD;
+  int64_t sC;                     // stride between the nC values of pC: a row-partitioned run finds one share of <y,y> per rank in
+                                  // the scalar slots that ride on the operand all-gather (GatherLayout::slot)
+};
+
+// Where a kernel that finishes its reduction in its last workgroup (common.h) leaves things: workgroup b stores its partial
+// at part[b] (the host offsets `part` per sweep launch), the last of `tickets` workgroups adds base[0..count) and stores the
+// total to tot (and to tot2 when non-null: the scalar slot of the operand exchange).
+struct MinresRed {
+  double* part;
+  double* base;
+  int count;
+  unsigned tickets;
+  unsigned* counter;
+  double* tot;
+  double* tot2;
 };
 
 __device__ __forceinline__ double sum_or_value(const double* p, int count, double* lds) {
   if (count == 1) return p[0];
   return block_sum_partials(p, count, lds);
+}
+
+// <y,y> of the previous KC: one value, or one share per rank (rank order, so every rank adds them alike)
+__device__ __forceinline__ double minres_yy(const MinresArgs& a) {
+  double bb = a.pC[0];
+  for (int r = 1; r < a.nC; ++r) bb += a.pC[(int64_t)r * a.sC];
+  return bb;
 }
 
 // Stopping tests of the iteration that has just completed (SciPy order).  S is a private copy.

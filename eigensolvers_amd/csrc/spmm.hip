@@ -208,25 +208,12 @@ int hipeig_block_pick_variant(hipeig_ctx* c, hipeig_csr* A, int K) {
   return A->last_block_variant = 2;
 }
 
-// All-gather of an interleaved block of width K: rank r's rows land at xb_full + r*stride*K (the layout the
-// remapped column indices address).  Single rank: the local block is the operand.
+// All-gather of an interleaved block of width K into the layout the remapped column indices address (the chunk-major
+// layout of the single-vector exchange, K doubles per position; comm.hip).  Single rank: the local block is the operand.
 int hipeig_block_allgather(hipeig_ctx* c, hipeig_csr* A, int K, const double* xb_local, const double** xb_full) {
   if (!c->collectives) { *xb_full = xb_local; return 0; }
-  const int64_t stride = A->col_stride, need = stride * c->nranks * BCOO_KMAX;
-  HIPEIG_REQUIRE(stride >= A->nrows, "operator was not prepared for this communicator");
-  if (c->xb_full_n < need) {
-    if (c->xb_full) HIPEIG_CHECK(hipFree(c->xb_full));
-    c->xb_full = nullptr; c->xb_full_n = 0;
-    HIPEIG_CHECK(hipMalloc((void**)&c->xb_full, (size_t)need * sizeof(double)));
-    c->xb_full_n = need;
-  }
-  double* mine = c->xb_full + (int64_t)c->rank * stride * K;
-  HIPEIG_CHECK(hipMemcpyAsync(mine, xb_local, (size_t)A->nrows * K * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  if (stride > A->nrows)                                 // padding rows of a shorter slab travel too: keep them finite
-    HIPEIG_CHECK(hipMemsetAsync(mine + A->nrows * K, 0, (size_t)(stride - A->nrows) * K * sizeof(double), c->stream));
-  if (hipeig_allgather_f64(c, mine, c->xb_full, (size_t)stride * K)) return 4;
-  *xb_full = c->xb_full;
-  return 0;
+  HIPEIG_REQUIRE(A->col_stride > 0 && A->gl.h * A->gl.nchunks >= A->nrows, "operator was not prepared for this communicator");
+  return hipeig_allgather_block(c, A->gl, K, xb_local, A->nrows, xb_full);
 }
 
 // ---- plain block product -------------------------------------------------------------------

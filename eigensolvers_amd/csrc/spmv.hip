@@ -116,7 +116,7 @@ rowabs_max_kernel(const int32_t* __restrict__ rowptr, const double* __restrict__
 }
 
 // Operand maximum for the fixed-point sweep: per-workgroup maxima into the context's fx area.
-#define HIPEIG_FX_AREA (8 * HIPEIG_MAX_PARTIALS)
+#define HIPEIG_FX_AREA (4 * HIPEIG_WIDE_PARTIALS)      // behind the three partial-sum areas of the MINRES kernels
 int hipeig_fixed_prepare(hipeig_ctx* c, const hipeig_csr* A, const double* xg, TcooView* t) {
   const int g = grid_for(A->gather_len, 8);
   double* area = c->d_partials + HIPEIG_FX_AREA;
@@ -141,7 +141,7 @@ TcooView hipeig_tcoow_view(const hipeig_csr* A) {
   if (const char* e = getenv("HIPEIG_TCOO_ABLATE")) t.ablate = atoi(e);   // timing experiments (wrong results)
   t.nrows = A->nrows;
   t.gather_len = A->gather_len;
-  t.win_lo = 0; t.win_hi = A->w_nwin; t.invert = 0; t.yinit = nullptr; t.raw_out = nullptr;
+  t.nrun = 0; t.yinit = nullptr; t.raw_out = nullptr;
   t.csplit = 1; t.part_base = 0; t.part_stride = 0;
   t.fx_xmax = nullptr; t.fx_count = 0; t.fx_bound = 0.0;
   return t;
@@ -157,7 +157,7 @@ TcooView hipeig_tcoo_view(const hipeig_csr* A) {
   if (const char* e = getenv("HIPEIG_TCOO_ABLATE")) t.ablate = atoi(e);   // timing experiments (wrong results)
   t.nrows = A->nrows;
   t.gather_len = A->gather_len;
-  t.win_lo = 0; t.win_hi = A->t_nwin; t.invert = 0; t.yinit = nullptr; t.raw_out = nullptr;
+  t.nrun = 0; t.yinit = nullptr; t.raw_out = nullptr;
   t.csplit = 1; t.part_base = 0; t.part_stride = 0;
   t.fx_xmax = nullptr; t.fx_count = 0; t.fx_bound = 0.0;
   return t;
@@ -211,69 +211,178 @@ static int tcoow_ensure_parts(hipeig_ctx* c, int64_t doubles) {
 
 int64_t hipeig_tcoow_part_stride(const hipeig_csr* A) { return (A->nrows + 63) & ~(int64_t)63; }
 
+void hipeig_phase_mark(hipeig_ctx* c, int k);
+const double* hipeig_gathered(hipeig_ctx* c);
+
+// The column windows of a partitioned TCOO-W operator by what they need:
+// set 0 - windows that lie entirely inside this rank's own column ranges (one range per chunk of the gathered layout):
+//         they can be swept as soon as the slice has been copied into the gathered buffer, while the exchange runs;
+// set 1 + k - the other windows whose last column belongs to chunk k: complete once chunk k has arrived.
+// Every set is at most two runs of consecutive windows (a chunk's windows minus the local run inside them).
+struct WindowSets {
+  int nset;                        // 1 + nchunks
+  int nrun[1 + HIPEIG_GATHER_MAX_CHUNKS];
+  int lo[1 + HIPEIG_GATHER_MAX_CHUNKS][4], hi[1 + HIPEIG_GATHER_MAX_CHUNKS][4];
+};
+
+static void tcoow_window_sets(const hipeig_ctx* c, const hipeig_csr* A, WindowSets* ws) {
+  const GatherLayout& gl = A->gl;
+  const int wb = A->w_wbits, nwin = A->w_nwin;
+  const int64_t W = (int64_t)1 << wb;
+  memset(ws, 0, sizeof(*ws));
+  ws->nset = 1 + gl.nchunks;
+  int prev_end = 0;                                   // first window not yet given to a chunk
+  for (int k = 0; k < gl.nchunks; ++k) {
+    // windows whose last position lies in chunk k: [prev_end, wend)
+    int wend = (k == gl.nchunks - 1) ? nwin : (int)(gl.cbase[k + 1] >> wb);      // window holding cbase[k+1] straddles: it waits for k+1
+    if (wend > nwin) wend = nwin;
+    if (wend < prev_end) wend = prev_end;
+    // own range inside chunk k, and the windows entirely inside it
+    const int64_t rows_lo = (int64_t)k * gl.h;
+    int64_t rows = A->nrows - rows_lo;
+    if (rows > gl.h) rows = gl.h;
+    int l0 = 0, l1 = 0;
+    if (rows > 0) {
+      const int64_t p0 = gl.cbase[k] + (int64_t)c->rank * gl.cstride(k), p1 = p0 + rows;
+      l0 = (int)((p0 + W - 1) >> wb); l1 = (int)(p1 >> wb);
+      if (l0 < prev_end) l0 = prev_end;
+      if (l1 > wend) l1 = wend;
+      if (l1 < l0) l1 = l0;
+    }
+    if (l1 > l0) {
+      const int q = ws->nrun[0]++;
+      ws->lo[0][q] = l0; ws->hi[0][q] = l1;
+      if (l0 > prev_end) { const int r = ws->nrun[1 + k]++; ws->lo[1 + k][r] = prev_end; ws->hi[1 + k][r] = l0; }
+      if (wend > l1) { const int r = ws->nrun[1 + k]++; ws->lo[1 + k][r] = l1; ws->hi[1 + k][r] = wend; }
+    } else if (wend > prev_end) {
+      const int r = ws->nrun[1 + k]++; ws->lo[1 + k][r] = prev_end; ws->hi[1 + k][r] = wend;
+    }
+    prev_end = wend;
+  }
+}
+
 // Allocate the slabs one product of A can need, so that no allocation happens later (a hipGraph
 // capture must not allocate).
 int hipeig_tcoow_reserve(hipeig_ctx* c, const hipeig_csr* A) {
   if (!A->w_idx) return 0;
   const int64_t stride = hipeig_tcoow_part_stride(A);
-  const int64_t need = (A->w_csplit > 1) ? (int64_t)(c->collectives ? 2 : 1) * A->w_csplit * stride
-                                         : (c->collectives ? A->nrows : 0);
+  const int nl = c->collectives ? 1 + A->gl.nchunks : 1;
+  const int64_t need = (A->w_csplit > 1) ? (int64_t)nl * A->w_csplit * stride : (c->collectives ? A->nrows : 0);
   return need > 0 ? tcoow_ensure_parts(c, need) : 0;
 }
 
-// Multi-GPU overlap for the TCOO-W layout.  The windows that lie entirely inside this rank's own
-// column range need only x_local, so they are swept while the all-gather of the other ranks'
-// slices runs on the communication stream; the raw partial sums go to ctx->ytmp.  The caller then
-// launches the remaining windows (`tv2`: inverted window range) - without column splits the
-// accumulators start from ytmp and the launch runs the epilogue; with column splits both launches
-// store raw slabs and the caller combines them.  Returns 1 when the split path was taken (tv2 / xg
-// set), 0 when the caller should use the plain all-gather + full sweep, -1 on error.
-int hipeig_tcoow_overlap_begin(hipeig_ctx* c, hipeig_csr* A, const double* x_local, TcooView* tv2, const double** xg) {
-  if (!c->collectives || !c->overlap || !A->w_idx || A->col_stride <= 0 || A->last_variant == 5) return 0;   // the fixed-point form needs max|x| of the whole operand first
-  const int64_t lo = (int64_t)c->rank * A->col_stride, hi = lo + A->nrows;
-  const int64_t W = (int64_t)1 << A->w_wbits;
-  const int cl0 = (int)((lo + W - 1) >> A->w_wbits), cl1 = (int)(hi >> A->w_wbits);
-  if (cl1 <= cl0) return 0;                             // no window is entirely local
+// Everything one TCOO-W product does before its epilogue-bearing launch, as a list of sweep launches:
+//   launch i covers the windows of tv[i]; wait[i] >= 0: the compute stream must first wait for that chunk of the
+//   operand exchange (hipeig_allgather_x_wait_chunk).
+// Without a communicator (or without the overlap) that is ONE launch over all windows after a plain exchange.  With it,
+// the exchange is started first and the launches are: this rank's own windows (under the exchange), then per chunk the
+// windows that chunk completes.  Accumulators: with column splits every launch stores its own raw
+// slabs (part_base = launch * csplit) and *ncombine > 0 tells the caller to add that many slabs in a combine kernel
+// that carries the epilogue; without, the launches hand their sums on through ctx->ytmp (raw_out -> yinit) and the
+// LAST launch carries the epilogue.
+struct TcoowPlan {
+  int nlaunch;
+  TcooView tv[2 + HIPEIG_GATHER_MAX_CHUNKS];
+  int wait[2 + HIPEIG_GATHER_MAX_CHUNKS];
+  int ncombine;
+  const double* xg;
+  bool overlapped;
+};
+
+int hipeig_tcoow_plan(hipeig_ctx* c, hipeig_csr* A, const double* x_local, TcoowPlan* P) {
   const int cs = A->w_csplit;
   const int64_t stride = hipeig_tcoow_part_stride(A);
-  if (tcoow_ensure_parts(c, cs > 1 ? 2 * cs * stride : A->nrows)) return -1;
-  if (hipeig_allgather_x_begin(c, x_local, A->nrows, A->col_stride)) return -1;
-  TcooView t = hipeig_tcoow_view(A);
-  t.win_lo = cl0; t.win_hi = cl1; t.invert = 0; t.yinit = nullptr; t.raw_out = c->ytmp;
-  t.csplit = cs; t.part_base = 0; t.part_stride = stride;
-  const int g = hipeig_spmv_grid(A, 4);
-  AxpyEpilogue none{0.0, 0.0, nullptr, nullptr};
-  for (int ub = 0; ub < A->w_nunits * cs; ub += g) {
-    t.unit_begin = ub;
-    // x_local - lo: global column j of the local range is x_local[j - lo]
-    hipLaunchKernelGGL(spmv_tcoow_kernel<0>, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t, x_local - lo, none);
+  P->nlaunch = 0; P->ncombine = 0; P->xg = nullptr; P->overlapped = false;
+  WindowSets ws;
+  bool split_sets = c->collectives && c->overlap && A->w_idx && A->col_stride > 0 && A->last_variant != 5;   // the fixed-point form needs max|x| of the whole operand first
+  if (split_sets) {
+    tcoow_window_sets(c, A, &ws);
+    int nonempty = 0;
+    for (int q = 0; q < ws.nset; ++q) nonempty += ws.nrun[q] > 0;
+    if (ws.nrun[0] == 0 && A->gl.nchunks == 1) split_sets = false;        // nothing to hide the exchange behind
+    if (nonempty <= 1 && ws.nrun[0] == 0) split_sets = false;
   }
-  if (hipGetLastError() != hipSuccess) { hipeig_set_error("local-window launch failed"); return -1; }
-  if (hipeig_allgather_x_end(c, xg)) return -1;
-  *tv2 = hipeig_tcoow_view(A);
-  tv2->win_lo = cl0; tv2->win_hi = cl1; tv2->invert = 1;
-  tv2->csplit = cs; tv2->part_stride = stride;
-  if (cs > 1) { tv2->yinit = nullptr; tv2->raw_out = c->ytmp; tv2->part_base = cs; }
-  else { tv2->yinit = c->ytmp; tv2->raw_out = nullptr; tv2->part_base = 0; }
-  return 1;
+  if (!split_sets) {
+    if (hipeig_allgather_x(c, A->gl, x_local, A->nrows, &P->xg)) return 4;
+    TcooView t = hipeig_tcoow_view(A);
+    if (cs > 1) {
+      if (tcoow_ensure_parts(c, cs * stride)) return 4;
+      t.csplit = cs; t.part_base = 0; t.part_stride = stride; t.raw_out = c->ytmp;
+      P->ncombine = cs;
+    }
+    P->tv[0] = t; P->wait[0] = -1; P->nlaunch = 1;
+    return 0;
+  }
+  int nl = 0;
+  for (int q = 0; q < ws.nset; ++q) nl += ws.nrun[q] > 0;
+  if (tcoow_ensure_parts(c, cs > 1 ? (int64_t)nl * cs * stride : A->nrows)) return 4;
+  if (hipeig_allgather_x_begin(c, A->gl, x_local, A->nrows)) return 4;
+  P->overlapped = true;
+  int li = 0;
+  for (int q = 0; q < ws.nset; ++q) {
+    if (ws.nrun[q] == 0) continue;
+    TcooView t = hipeig_tcoow_view(A);
+    t.nrun = ws.nrun[q];
+    for (int r = 0; r < ws.nrun[q]; ++r) { t.run_lo[r] = ws.lo[q][r]; t.run_hi[r] = ws.hi[q][r]; }
+    t.csplit = cs; t.part_stride = stride;
+    if (cs > 1) { t.yinit = nullptr; t.raw_out = c->ytmp; t.part_base = li * cs; }
+    else {
+      t.part_base = 0;
+      t.yinit = (li > 0) ? c->ytmp : nullptr;
+      t.raw_out = (li + 1 < nl) ? c->ytmp : nullptr;
+    }
+    P->tv[li] = t;
+    P->wait[li] = (q == 0) ? -1 : q - 1;
+    ++li;
+  }
+  P->nlaunch = nl;
+  P->ncombine = (cs > 1) ? nl * cs : 0;
+  // a set without windows still has to be waited for by the launch that follows it; the last launch waits for the
+  // last chunk in any case (it - or the combine kernel behind it - may read the scalar slots riding on that chunk)
+  P->wait[nl - 1] = A->gl.nchunks - 1;
+  P->xg = nullptr;                                           // set by the caller after the first wait: hipeig_gathered()
+  return 0;
 }
 
-// Everything before the last TCOO-W launch of one product: the operand exchange (overlapped with the
-// local windows when possible) and the view that launch must use.  *ncombine > 0 means the launches
-// leave that many raw slabs in ctx->ytmp and the caller must run a combine kernel with its epilogue.
-int hipeig_tcoow_prepare(hipeig_ctx* c, hipeig_csr* A, const double* x_local, TcooView* tv, const double** xg, int* ncombine) {
-  const int ov = hipeig_tcoow_overlap_begin(c, A, x_local, tv, xg);
-  if (ov < 0) return 4;
-  if (ov == 0) {
-    if (hipeig_allgather_x(c, x_local, A->nrows, A->col_stride, xg)) return 4;
-    *tv = hipeig_tcoow_view(A);
-    if (A->w_csplit > 1) {
-      const int64_t stride = hipeig_tcoow_part_stride(A);
-      if (tcoow_ensure_parts(c, A->w_csplit * stride)) return 4;
-      tv->csplit = A->w_csplit; tv->part_base = 0; tv->part_stride = stride; tv->raw_out = c->ytmp;
+// Raw (epilogue-free) launch of plan entry i, all its sweeps.
+static void tcoow_launch_raw(hipeig_ctx* c, hipeig_csr* A, TcooView t, const double* xg, int g, int fixed) {
+  AxpyEpilogue none{0.0, 0.0, nullptr, nullptr};
+  for (int ub = 0; ub < A->w_nunits * t.csplit; ub += g) {
+    t.unit_begin = ub;
+    if (fixed) hipLaunchKernelGGL(spmv_tcoow_kernel<1>, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t, xg, none);
+    else hipLaunchKernelGGL(spmv_tcoow_kernel<0>, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t, xg, none);
+  }
+}
+
+// Runs every launch of the plan that carries no epilogue; returns through *last the view the caller must launch with its
+// own epilogue kernel (nullptr when a combine launch carries it: *ncombine slabs in ctx->ytmp), *xg the operand.
+int hipeig_tcoow_run_plan(hipeig_ctx* c, hipeig_csr* A, const double* x_local, int fixed, TcooView* last, bool* has_last,
+                          const double** xg, int* ncombine) {
+  TcoowPlan P;
+  if (hipeig_tcoow_plan(c, A, x_local, &P)) return 4;
+  const int g = hipeig_spmv_grid(A, 4);
+  const double* x = P.overlapped ? hipeig_gathered(c) : P.xg;
+  const int nraw = P.ncombine ? P.nlaunch : P.nlaunch - 1;
+  if (fixed) {                                              // never overlapped (hipeig_tcoow_plan): max|x| of the whole operand first
+    HIPEIG_REQUIRE(!P.overlapped && P.nlaunch == 1, "the fixed-point sweep takes the plain exchange");
+    if (hipeig_fixed_prepare(c, A, x, &P.tv[0])) return 4;
+  }
+  bool marked = false;
+  for (int i = 0; i < P.nlaunch; ++i) {
+    if (P.wait[i] >= 0) {
+      if (hipeig_allgather_x_wait_chunk(c, A->gl, P.wait[i])) return 4;
+      if (P.overlapped && !marked) { hipeig_phase_mark(c, 2); marked = true; }
+    }
+    if (i < nraw) {
+      tcoow_launch_raw(c, A, P.tv[i], x, g, fixed);
+      if (P.overlapped && i == 0) hipeig_phase_mark(c, 1);
     }
   }
-  *ncombine = (tv->csplit > 1) ? tv->part_base + tv->csplit : 0;
+  if (hipGetLastError() != hipSuccess) { hipeig_set_error("sweep launch failed"); return 4; }
+  *has_last = (P.ncombine == 0);
+  *last = P.tv[P.nlaunch - 1];
+  *xg = x;
+  *ncombine = P.ncombine;
   return 0;
 }
 
@@ -291,21 +400,24 @@ static int launch_spmv(hipeig_ctx* c, hipeig_csr* A, double a_self, double a_sum
   const int g = hipeig_spmv_grid(A, variant);
   if (variant == 4) {
     TcooView t;
+    bool has_last = true;
     int ncombine = 0;
-    if (hipeig_tcoow_prepare(c, A, x, &t, &xg, &ncombine)) return 4;
-    if (fixed && hipeig_fixed_prepare(c, A, xg, &t)) return 4;
-    for (int ub = 0; ub < A->w_nunits * t.csplit; ub += g) {           // one launch per sweep
-      t.unit_begin = ub;
-      if (fixed) hipLaunchKernelGGL(spmv_tcoow_kernel<1>, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t, xg, epi);
-      else hipLaunchKernelGGL(spmv_tcoow_kernel<0>, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t, xg, epi);
+    if (hipeig_tcoow_run_plan(c, A, x, fixed ? 1 : 0, &t, &has_last, &xg, &ncombine)) return 4;
+    if (has_last) {
+      for (int ub = 0; ub < A->w_nunits * t.csplit; ub += g) {           // one launch per sweep
+        t.unit_begin = ub;
+        if (fixed) hipLaunchKernelGGL(spmv_tcoow_kernel<1>, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t, xg, epi);
+        else hipLaunchKernelGGL(spmv_tcoow_kernel<0>, dim3(g), dim3(TCOOW_THREADS), hipeig_tcoow_lds_bytes(A), c->stream, t, xg, epi);
+      }
     }
     if (ncombine)
       hipLaunchKernelGGL(spmv_tcoow_combine_kernel, dim3(grid_for(A->nrows, 2)), dim3(HIPEIG_BLOCK), 0, c->stream,
                          c->ytmp, ncombine, t.part_stride, A->nrows, epi);
     HIPEIG_CHECK(hipGetLastError());
+    hipeig_phase_mark(c, 3);
     return 0;
   }
-  if (hipeig_allgather_x(c, x, A->nrows, A->col_stride, &xg)) return 4;
+  if (hipeig_allgather_x(c, A->gl, x, A->nrows, &xg)) return 4;
   const CsrView v = hipeig_csr_view(A);
   if (variant == 3) {
     TcooView t = hipeig_tcoo_view(A);
@@ -318,6 +430,7 @@ static int launch_spmv(hipeig_ctx* c, hipeig_csr* A, double a_self, double a_sum
   else
     hipLaunchKernelGGL(spmv_stream_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, v, xg, epi);
   HIPEIG_CHECK(hipGetLastError());
+  hipeig_phase_mark(c, 3);
   return 0;
 }
 
@@ -348,7 +461,7 @@ static int launch_spmv_pair(hipeig_ctx* c, hipeig_csr* A, double zr, double zi, 
       TcooView t = hipeig_tcoow_view(A);
       t.idx = A->p_idx; t.val = A->p_val; t.off = A->p_off;
       t.nunits = A->p_nunits; t.nwin = A->p_nwin; t.wbits = A->p_wbits; t.rw = A->p_rw;
-      t.win_lo = 0; t.win_hi = A->p_nwin;
+      t.nrun = 0;
       PairEpilogue epi{ar, ai, as, xr + A->row_offset, xi + A->row_offset, yr, yi};
       int g = A->p_wgs_per_sweep < A->p_nunits ? A->p_wgs_per_sweep : A->p_nunits;
       const size_t lds = (size_t)2 * A->p_rw * sizeof(double) + ((size_t)A->p_nwin + 2) * sizeof(uint32_t);
@@ -718,13 +831,16 @@ int hipeig_csr_pick_variant(hipeig_ctx* c, hipeig_csr* A) {
 
 // ---- layout preparation ------------------------------------------------------------------
 __global__ void remap_cols_kernel(int32_t* __restrict__ col, int64_t nnz, const int64_t* __restrict__ offs,
-                                  int nranks, int64_t stride) {
+                                  GatherLayout gl) {
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += step) {
     const int64_t j = col[p];
-    int r = 0;
-    while (r + 1 < nranks && j >= offs[r + 1]) ++r;
-    col[p] = (int32_t)(r * stride + (j - offs[r]));
+    int lo = 0, hi = gl.nranks - 1;                    // owner rank: offs[r] <= j < offs[r + 1] (empty slabs have equal offsets)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (j >= offs[mid]) lo = mid; else hi = mid - 1;
+    }
+    col[p] = (int32_t)gl.pos(lo, j - offs[lo]);
   }
 }
 
@@ -754,25 +870,25 @@ int hipeig_csr_finalize(hipeig_ctx* c, hipeig_csr* A, const int32_t* rowptr32) {
 
   A->gather_len = A->ncols;
   // distributed: gather row counts, size x_full and remap global columns to its layout
-  int64_t stride = 0;
-  if (hipeig_comm_setup_rows(c, A->nrows, &stride)) return 4;
+  if (hipeig_comm_setup_rows(c, A->nrows, &A->gl)) return 4;
   if (c->collectives) {
+    HIPEIG_REQUIRE(c->nranks <= HIPEIG_MAX_RANKS, "too many ranks");
     std::vector<int64_t> offs(c->nranks + 1, 0);
     for (int k = 0; k < c->nranks; ++k) offs[k + 1] = offs[k] + c->row_counts[k];
     HIPEIG_REQUIRE(offs[c->nranks] == A->ncols, "row counts over ranks must add up to ncols");
     HIPEIG_REQUIRE(offs[c->rank] == A->row_offset, "row_offset does not match the rank order");
-    HIPEIG_REQUIRE(stride * c->nranks < (int64_t)1 << 31, "gathered operand too long for int32 columns");
+    HIPEIG_REQUIRE(A->gl.total() < (int64_t)1 << 31, "gathered operand too long for int32 columns");
     int64_t* d_offs = (int64_t*)(c->d_scalars + 1024);
     HIPEIG_CHECK(hipMemcpyAsync(d_offs, offs.data(), sizeof(int64_t) * (c->nranks + 1),
                                 hipMemcpyHostToDevice, c->stream));
     if (A->nnz > 0) {
       hipLaunchKernelGGL(remap_cols_kernel, dim3(2048), dim3(HIPEIG_BLOCK), 0, c->stream,
-                         A->d_col, A->nnz, d_offs, c->nranks, stride);
+                         A->d_col, A->nnz, d_offs, A->gl);
       HIPEIG_CHECK(hipGetLastError());
     }
     HIPEIG_CHECK(hipStreamSynchronize(c->stream));
-    A->col_stride = stride;
-    A->gather_len = stride * c->nranks;
+    A->col_stride = A->gl.h;
+    A->gather_len = A->gl.total();
   }
   return 0;
 }
@@ -842,6 +958,24 @@ extern "C" int hipeig_csr_destroy(hipeig_ctx* c, hipeig_csr* A) {
     if (A->bl[q].off) hipFree(A->bl[q].off);
   }
   free(A);
+  return 0;
+}
+
+// Layout constants of the blocked copy the product runs on (what a committed counter profile is only valid for):
+// out[0] = kernel variant of the last launch, [1] rows per row block, [2] window bits, [3] row blocks, [4] windows,
+// [5] column splits, [6] workgroups per sweep launch, [7] threads per workgroup, [8] batch unroll, [9] chunks of the
+// operand exchange, [10] rows per (rank, chunk) of the gathered layout (0: not partitioned)
+extern "C" int hipeig_csr_layout_info(hipeig_csr* A, int64_t out[12]) {
+  memset(out, 0, 12 * sizeof(int64_t));
+  out[0] = A->last_variant;
+  if (A->last_variant == 4 || A->last_variant == 5) {
+    out[1] = A->w_rw; out[2] = A->w_wbits; out[3] = A->w_nunits; out[4] = A->w_nwin; out[5] = A->w_csplit;
+    out[6] = A->w_wgs_per_sweep; out[7] = TCOOW_THREADS; out[8] = TCOO_UNROLL;
+  } else if (A->last_variant == 3) {
+    out[1] = A->t_rw; out[2] = A->t_wbits; out[3] = A->t_nunits; out[4] = A->t_nwin; out[6] = A->t_wgs_per_sweep;
+    out[7] = HIPEIG_BLOCK; out[8] = TCOO_UNROLL;
+  }
+  if (A->col_stride > 0) { out[9] = A->gl.nchunks; out[10] = A->gl.h; }
   return 0;
 }
 

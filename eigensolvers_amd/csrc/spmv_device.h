@@ -148,10 +148,11 @@ struct TcooView {
   int32_t ablate;                        // timing experiments only: 1 = skip gathers, 2 = skip LDS adds,
                                          // 4 = skip the value stream, 8 = gather from window 0 only
   int64_t nrows, gather_len;
-  // split sweeps (multi-GPU overlap): process the windows inside [win_lo, win_hi) - or, with
-  // `invert`, the windows outside it; start the accumulators from yinit instead of zero;
+  // split sweeps (multi-GPU overlap): process only the windows of `nrun` ascending, disjoint runs
+  // [run_lo[i], run_hi[i]) (nrun = 0: all windows); start the accumulators from yinit instead of zero;
   // store raw sums to raw_out instead of running the epilogue.  Defaults: all windows, 0, no.
-  int32_t win_lo, win_hi, invert;
+  int32_t nrun;
+  int32_t run_lo[4], run_hi[4];
   const double* yinit;
   double* raw_out;
   // column splits (TCOO-W only): when an operator (slab) has fewer row blocks than the GPU has CUs,
@@ -409,8 +410,8 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
     int cw[TCOO_UNROLL];                                                               \
     _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j) {                          \
       const uint32_t q = (BASE) + lane + jstride * j;                                       \
-      /* padding lanes (q >= send) must not move the cursor: in an inverted sweep it would run into */ \
-      /* the skipped window range and the next part's first elements would gather from there       */ \
+      /* padding lanes (q >= send) must not move the cursor: it would run into the windows skipped  */ \
+      /* between two runs and the next run's first elements would gather from there                */ \
       while (q < send && c + 1 < T.nwin && q >= offL[c + 1]) ++c;                      \
       cw[j] = c;                                                                       \
     }                                                                                  \
@@ -443,11 +444,11 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
       _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j) sink += V[j] + (double)ID[j]; \
     }                                                                                  \
   }
-  // stream ranges of this launch: all windows, the windows in [win_lo, win_hi), or those outside
-  const int nparts = T.invert ? 2 : 1;
+  // stream ranges of this launch: all windows, or the windows of the runs
+  const int nparts = T.nrun ? T.nrun : 1;
   for (int part = 0; part < nparts; ++part) {
-    uint32_t sbeg = T.invert ? (part == 0 ? offL[0] : offL[T.win_hi]) : offL[T.win_lo];
-    uint32_t send = T.invert ? (part == 0 ? offL[T.win_lo] : offL[T.nwin]) : offL[T.win_hi];
+    uint32_t sbeg = T.nrun ? offL[T.run_lo[part]] : offL[0];
+    uint32_t send = T.nrun ? offL[T.run_hi[part]] : offL[T.nwin];
     if (T.csplit > 1) {                              // this workgroup's share of the range (64-element granules)
       const uint64_t len = send - sbeg;
       const uint32_t b0 = sbeg + (uint32_t)((len * (uint64_t)cs / (uint64_t)T.csplit) & ~(uint64_t)63);
@@ -455,7 +456,7 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
       sbeg = b0; send = b1;
     }
     uint32_t base = sbeg + wave_off;
-    if (part == 1 && c < T.win_hi) c = T.win_hi;       // second part of an inverted sweep starts behind the skipped windows
+    if (T.nrun && c < T.run_lo[part]) c = T.run_lo[part];      // a run starts behind the windows skipped in front of it
     if (base < send) {
       TCOO_LOAD(idA, vA, base)
       while (true) {

@@ -52,11 +52,15 @@ def world_from_env():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-# ---- rendezvous: a stdlib TCP exchange of RCCL's 128-byte unique id ------------------------------
-# Under ``torch.distributed.run`` the launcher's own store already listens on MASTER_PORT, so the
-# exchange uses a port derived from it: rank 0 binds the first free one of a short deterministic
-# candidate list, the other ranks try the candidates until one answers with the expected greeting.
-_MAGIC = b"HIPEIG-RDZV-1"
+# ---- rendezvous: a stdlib TCP group ------------------------------------------------------------------
+# Rank 0 listens, every other rank connects once and the sockets stay open for the life of the process; all that
+# ever travels are small records (RCCL's 128-byte unique id, hipIpc memory handles of the direct all-gather, a few
+# scalars of a benchmark).  Under ``torch.distributed.run`` the launcher's own store already listens on MASTER_PORT,
+# so the group uses a port derived from it: rank 0 binds the first free one of a short deterministic candidate
+# list, the other ranks try the candidates until one answers the greeting.  The listener binds MASTER_ADDR only
+# (127.0.0.1 on one node); the greeting carries the launcher's run id and port, which keeps two jobs on one host
+# apart - it is not an authentication scheme.
+_MAGIC = b"HIPEIG-RDZV-2"
 
 
 def _candidate_ports():
@@ -67,78 +71,224 @@ def _candidate_ports():
     return [20000 + (mp * 7 + 13 + 101 * k) % 20000 for k in range(8)]
 
 
-_exchange_seq = 0
-
-
 def _run_token():
     return (os.environ.get("TORCHELASTIC_RUN_ID", "none") + ":" + os.environ.get("MASTER_PORT", "29511")).encode()
 
 
-def exchange_bytes(payload, nbytes, rank, world, timeout=300.0):
-    """Rank 0 hands ``payload`` (``nbytes`` bytes) to every other rank over TCP on MASTER_ADDR; returns it.
-    No third-party module involved (the north star's "no PyTorch" covers the rendezvous too)."""
-    import socket
-    import time
-    if world == 1:
-        return bytes(payload)
-    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-    # the n-th exchange of this job only talks to the n-th exchange of the other ranks: a rank that is already one
-    # exchange ahead is turned away (and retries) instead of being handed the previous record
-    global _exchange_seq
-    _exchange_seq += 1
-    token = _MAGIC + b"|" + _run_token() + b"#" + str(_exchange_seq).encode()
-    if rank == 0:
-        srv = None
-        for port in _candidate_ports():
+def _send_msg(sock, payload):
+    sock.sendall(len(payload).to_bytes(8, "little") + payload)
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("rendezvous: peer closed the connection")
+        buf += chunk
+    return bytes(buf)
+
+
+def _recv_msg(sock, limit=1 << 26):
+    n = int.from_bytes(_recv_exact(sock, 8), "little")
+    if n > limit:
+        raise ConnectionError(f"rendezvous: implausible record length {n}")
+    return _recv_exact(sock, n)
+
+
+class TcpGroup:
+    """All ranks of the job joined by TCP connections to rank 0 (star).  ``allgather(blob)`` returns every rank's blob in
+    rank order on every rank; ``barrier()`` is an all-gather of nothing.  Collective: every rank makes the same calls."""
+
+    def __init__(self, rank, world, timeout=300.0):
+        import socket
+        import time
+        self.rank, self.world = int(rank), int(world)
+        self.peers = {}                 # rank 0: {peer rank: socket}
+        self.sock = None                # other ranks: the socket to rank 0
+        if self.world == 1:
+            return
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        hello = _MAGIC + b"|" + _run_token() + b"|"
+        if self.rank == 0:
+            srv = None
+            for port in _candidate_ports():
+                try:
+                    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind((addr, port))
+                    break
+                except OSError:
+                    srv.close()
+                    srv = None
+            if srv is None:
+                raise RuntimeError(f"rendezvous: none of the ports {_candidate_ports()} is free on {addr}")
+            srv.listen(self.world + 8)
+            deadline = time.time() + timeout
             try:
-                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-                srv.bind((addr, port))
-                break
-            except OSError:
-                srv.close()
-                srv = None
-        if srv is None:
-            raise RuntimeError(f"rendezvous: none of the ports {_candidate_ports()} is free on {addr}")
-        srv.listen(world)
-        srv.settimeout(timeout)
-        served = set()
-        try:
-            while len(served) < world - 1:
-                conn, _ = srv.accept()
-                with conn:
-                    conn.settimeout(10.0)
+                while len(self.peers) < self.world - 1:
+                    srv.settimeout(max(0.1, deadline - time.time()))
                     try:
-                        hello = conn.recv(256)
-                    except OSError:
-                        continue
-                    if not hello.startswith(token + b"|"):
-                        continue                              # a stranger on our port: ignore
-                    peer = int(hello[len(token) + 1:].decode())
-                    conn.sendall(token + b"|" + bytes(payload))
-                    served.add(peer)
-        finally:
-            srv.close()
-        return bytes(payload)
-    deadline = time.time() + timeout
-    while time.time() < deadline:
-        for port in _candidate_ports():
+                        conn, _ = srv.accept()
+                    except socket.timeout:
+                        missing = sorted(set(range(1, self.world)) - set(self.peers))
+                        raise TimeoutError(f"rendezvous: ranks {missing} did not join within {timeout:.0f} s") from None
+                    try:
+                        conn.settimeout(10.0)
+                        msg = _recv_msg(conn, 4096)          # the whole greeting, however TCP cut it up
+                        if not msg.startswith(hello):
+                            raise ValueError("a stranger on our port")
+                        peer = int(msg[len(hello):].decode())
+                        if not 0 < peer < self.world or peer in self.peers:
+                            raise ValueError("rank out of range or seen twice")
+                        _send_msg(conn, b"OK")
+                        if _recv_msg(conn, 16) != b"ACK":    # the peer has our answer: only now does it count as joined
+                            raise ValueError("no acknowledgement")
+                        conn.settimeout(timeout)
+                        conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        self.peers[peer] = conn
+                    except (OSError, ValueError, ConnectionError):
+                        conn.close()                          # garbled, truncated or foreign greeting: keep listening
+            finally:
+                srv.close()
+            return
+        deadline = time.time() + timeout
+        while time.time() < deadline:
+            for port in _candidate_ports():
+                c = None
+                try:
+                    c = socket.create_connection((addr, port), timeout=2.0)
+                    c.settimeout(10.0)
+                    _send_msg(c, hello + str(self.rank).encode())
+                    if _recv_msg(c, 16) != b"OK":
+                        raise ConnectionError("not our listener")
+                    _send_msg(c, b"ACK")
+                    c.settimeout(timeout)
+                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    self.sock = c
+                    return
+                except (OSError, ConnectionError):
+                    if c is not None:
+                        c.close()
+            time.sleep(0.05)
+        raise TimeoutError(f"rendezvous: rank {self.rank} found no listener of rank 0 within {timeout:.0f} s")
+
+    def allgather(self, blob):
+        blob = bytes(blob)
+        if self.world == 1:
+            return [blob]
+        if self.rank == 0:
+            parts = [blob] + [_recv_msg(self.peers[r]) for r in range(1, self.world)]
+            packed = b"".join(len(p).to_bytes(8, "little") + p for p in parts)
+            for r in range(1, self.world):
+                _send_msg(self.peers[r], packed)
+            return parts
+        _send_msg(self.sock, blob)
+        packed = _recv_msg(self.sock)
+        parts, o = [], 0
+        for _ in range(self.world):
+            n = int.from_bytes(packed[o:o + 8], "little")
+            parts.append(packed[o + 8:o + 8 + n])
+            o += 8 + n
+        return parts
+
+    def bcast(self, blob):
+        """Rank 0's blob on every rank."""
+        return self.allgather(blob if self.rank == 0 else b"")[0]
+
+    def barrier(self):
+        self.allgather(b"")
+
+    def close(self):
+        for s in list(self.peers.values()) + ([self.sock] if self.sock else []):
             try:
-                with socket.create_connection((addr, port), timeout=2.0) as c:
-                    c.sendall(token + b"|" + str(rank).encode())
-                    buf = b""
-                    want = len(token) + 1 + nbytes
-                    while len(buf) < want:
-                        chunk = c.recv(want - len(buf))
-                        if not chunk:
-                            break
-                        buf += chunk
-                    if len(buf) == want and buf.startswith(token + b"|"):
-                        return buf[len(token) + 1:]
+                s.close()
             except OSError:
                 pass
-        time.sleep(0.05)
-    raise TimeoutError(f"rendezvous: rank {rank} got no unique id from rank 0 within {timeout:.0f} s")
+        self.peers, self.sock = {}, None
+
+
+_group = None
+
+
+def tcp_group(rank=None, world=None, timeout=300.0):
+    """The process-wide TcpGroup (created on first use; collective)."""
+    global _group
+    if rank is None or world is None:
+        rank, world, _ = world_from_env()
+    if _group is None or (_group.rank, _group.world) != (int(rank), int(world)):
+        _group = TcpGroup(rank, world, timeout)
+    return _group
+
+
+def exchange_bytes(payload, nbytes, rank, world, timeout=300.0):
+    """Rank 0 hands ``payload`` (``nbytes`` bytes) to every other rank; returns it.  No third-party module involved (the
+    north star's "no PyTorch" covers the rendezvous too)."""
+    if world == 1:
+        return bytes(payload)
+    got = tcp_group(rank, world, timeout).bcast(payload)
+    if len(got) != nbytes:
+        raise RuntimeError(f"rendezvous: expected {nbytes} bytes from rank 0, got {len(got)}")
+    return got
+
+
+def free_port(addr="127.0.0.1"):
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind((addr, 0))
+        return s.getsockname()[1]
+
+
+def launch_local(argv, nproc, timeout=None, env_extra=None):
+    """Start ``nproc`` copies of ``python argv...`` on this node, one rank per GPU, and wait for them - what
+    ``torch.distributed.run`` does for this package, without torch.  The parent must not have touched the GPU (it does
+    not here: importing this module initialises nothing).  Each child gets RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT and a fresh rendezvous port; every device stays visible in every child (the direct
+    all-gather maps its peers' buffers), rank r uses device LOCAL_RANK.  Rank 0's stdout is returned; the other ranks'
+    stdout goes to stderr.  Returns (exit code, rank 0's stdout): non-zero as soon as any rank failed, in which case the
+    rest are terminated."""
+    import subprocess
+    import time
+    port, rdzv = free_port(), free_port()
+    procs = []
+    for r in range(nproc):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIPEIG_RDZV_PORT=str(rdzv),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    deadline = None if timeout is None else time.time() + timeout
+    out0, rc, live = b"", 0, set(range(nproc))
+    try:
+        import threading
+        box = {}
+        reader = threading.Thread(target=lambda: box.setdefault("out", procs[0].stdout.read()), daemon=True)
+        reader.start()
+        while live and rc == 0:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is not None:
+                    live.discard(r)
+                    if code != 0:
+                        rc = code if code > 0 else 1
+                        print(f"launch_local: rank {r} exited with status {code}", file=sys.stderr)
+            if deadline is not None and time.time() > deadline:
+                rc = 124
+                print(f"launch_local: timeout after {timeout:.0f} s", file=sys.stderr)
+            time.sleep(0.05)
+    finally:
+        for r in live:                      # a failed or timed-out job: stop exactly the children started here
+            procs[r].terminate()
+        for r in live:
+            try:
+                procs[r].wait(10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        reader.join(5)
+        out0 = box.get("out", b"") or b""
+    return rc, out0.decode("utf-8", "replace")
 
 
 def attach_rccl(ctx, rank=None, world=None):
@@ -151,6 +301,71 @@ def attach_rccl(ctx, rank=None, world=None):
         uid = exchange_bytes(uid, 128, rank, world)
         ctx.attach_comm(world, rank, uid)
     return rank, world
+
+
+def gathered_capacity(N, world):
+    """Doubles the gathered operand of an N-column operator split over ``world`` ranks can take (upper bound of the
+    library's chunk-major layout: slices padded to whole column windows, one scalar line per rank and chunk)."""
+    rows = -(-int(N) // int(world))
+    return int(world) * (rows + 4 * (1 << 17) + 64) + 4096
+
+
+def enable_direct_gather(ctx, capacity_doubles, rank=None, world=None):
+    """Set up the direct operand exchange (peer writes over every xGMI link at once, csrc/comm_direct.hip) next to the
+    RCCL communicator of ``ctx``: every rank allocates its buffers, the hipIpc records travel over the TCP group and
+    every rank maps its peers.  Collective.  Returns True when every rank succeeded; on any failure (no peer access, IPC
+    refused) all ranks stay on RCCL and the reason is printed on stderr."""
+    if rank is None or world is None:
+        rank, world, _ = world_from_env()
+    grp = tcp_group(rank, world)
+    rec, err = b"", ""
+    try:
+        rec = ctx.direct_alloc(capacity_doubles)
+    except Exception as exc:                                    # noqa: BLE001 - reported, every rank falls back together
+        err = f"alloc: {exc}"
+    recs = grp.allgather(rec)
+    ok = all(len(r) == 128 for r in recs)
+    if ok:
+        try:
+            ctx.direct_attach(recs)
+        except Exception as exc:                                # noqa: BLE001
+            err = f"attach: {exc}"
+            ok = False
+    oks = grp.allgather(b"1" if ok else b"0")
+    if all(o == b"1" for o in oks):
+        return True
+    if err:
+        print(f"[hipeig rank {rank}] direct exchange unavailable ({err}); staying on RCCL", file=sys.stderr)
+    return False
+
+
+def choose_gather_backend(ctx, H, group, reps=5):
+    """Time ``reps`` products of the partitioned operator ``H`` with each exchange backend, check that they give the same
+    result (to rounding: the blocked sweep adds a row's terms in no fixed order), and switch every rank to the faster one (max over ranks decides, so all ranks agree).  The direct
+    backend must have been attached (``enable_direct_gather``).  Returns a record of what was measured."""
+    import numpy as np
+    from .hip_vector import HipVector
+    n = H.nrows
+    x = HipVector(np.random.default_rng(4242 + ctx.rank).standard_normal(n), ctx=ctx)
+    y = {}
+    times = {}
+    for name in ("rccl", "direct"):
+        ctx.set_gather_backend(name)
+        out = ctx.alloc(n)
+        H.apply_shifted(0.0, x._buf, out)                       # warm-up (layout, buffers)
+        group.barrier()
+        ctx.timer_start()
+        for _ in range(reps):
+            H.apply_shifted(0.0, x._buf, out)
+        times[name] = group.allmax(ctx.timer_stop() / reps)
+        y[name] = HipVector(out).array
+    scale = float(np.max(np.abs(y["rccl"]))) if n else 0.0
+    same = bool(np.all(np.abs(y["rccl"] - y["direct"]) <= 1e-12 * scale)) and ctx.gather_info()["wait_error"] == 0
+    same = group.allmax(0.0 if same else 1.0) == 0.0
+    pick = "direct" if (same and times["direct"] < times["rccl"]) else "rccl"
+    ctx.set_gather_backend(pick)
+    return {"rccl_ms": round(times["rccl"], 4), "direct_ms": round(times["direct"], 4), "results_agree": same,
+            "chosen": pick, "reps": reps}
 
 
 class DeviceGroup:

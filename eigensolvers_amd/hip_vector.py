@@ -76,6 +76,47 @@ class HipContext:
         _lib.call("hipeig_comm_init_loopback", self.handle, group_handle, int(rank))
         self.nranks, self.rank = int(nranks), int(rank)
 
+    # ---- operand exchange of a row-partitioned product -------------------------------------------
+    GATHER_BACKENDS = {0: "rccl", 1: "direct"}
+
+    def direct_alloc(self, capacity_doubles):
+        """This rank's buffers for the direct exchange; returns its 128-byte hipIpc record."""
+        buf = C.create_string_buffer(128)
+        _lib.call("hipeig_direct_alloc", self.handle, int(capacity_doubles), C.cast(buf, C.c_void_p))
+        return bytes(buf.raw)
+
+    def direct_attach(self, records):
+        """Map the peers' buffers: ``records`` = every rank's 128-byte record in rank order."""
+        blob = b"".join(records)
+        buf = C.create_string_buffer(blob, len(blob))
+        _lib.call("hipeig_direct_attach", self.handle, C.cast(buf, C.c_void_p))
+
+    def set_gather_backend(self, name):
+        code = {v: k for k, v in self.GATHER_BACKENDS.items()}[name]
+        _lib.call("hipeig_comm_set_gather_backend", self.handle, code)
+
+    def gather_info(self):
+        info = (C.c_int64 * 8)()
+        _lib.call("hipeig_comm_gather_info", self.handle, info)
+        return {"backend": self.GATHER_BACKENDS[int(info[0])], "direct_attached": bool(info[1]), "capacity": int(info[2]),
+                "exchanges": int(info[3]), "wait_error": int(info[4]), "chunks_override": int(info[5])}
+
+    def phase_timing(self, on):
+        _lib.call("hipeig_phase_timing", self.handle, 1 if on else 0)
+
+    def phase_times(self):
+        """ms of the most recent partitioned product: exchange, own-window sweep, remaining sweep, whole product, idle gap
+        (None where the phase did not occur)."""
+        out = (C.c_double * 8)()
+        _lib.call("hipeig_phase_get", self.handle, out)
+        names = ("gather_ms", "local_sweep_ms", "remote_sweep_ms", "product_ms", "idle_before_first_chunk_ms")
+        return {k: (float(out[i]) if out[i] >= 0 else None) for i, k in enumerate(names)}
+
+    def allreduce_ms(self, count=2, reps=50):
+        out = C.c_double()
+        _lib.call("hipeig_comm_bench_allreduce", self.handle, int(count), int(reps), C.byref(out))
+        return float(out.value)
+
     def set_partitioned(self, flag):
         """False: replica mode - whole operators and vectors on every rank, no implicit collectives;
         only ``allreduce_vector`` exchanges data (FEAST contour replicas)."""
@@ -251,6 +292,14 @@ class HipCsrOperator:
         _lib.call("hipeig_csr_block_info", self.handle, info)
         return {"variant": self.BLOCK_VARIANTS[int(info[0])], "row_blocks": int(info[1]), "windows": int(info[2]),
                 "rows_per_block": int(info[3])}
+
+    def layout_info(self):
+        """Layout constants of the blocked copy the last product ran on (a counter profile is valid for these only)."""
+        out = (C.c_int64 * 12)()
+        _lib.call("hipeig_csr_layout_info", self.handle, out)
+        keys = ("variant", "rows_per_block", "window_bits", "row_blocks", "windows", "column_splits", "workgroups_per_launch",
+                "threads", "unroll", "exchange_chunks", "rows_per_rank_chunk")
+        return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def launches_per_apply(self):
         """Kernel launches (sweeps) one product takes with the variant last used."""

@@ -50,9 +50,9 @@ int hipeig_comm_library(char* path, int path_len);
 int hipeig_comm_init(hipeig_ctx* ctx, int nranks, int rank, const void* id128);
 int hipeig_comm_destroy(hipeig_ctx* ctx);
 int hipeig_comm_info(hipeig_ctx* ctx, int* nranks, int* rank);
-/* stats[0] = collectives (operand all-gathers + all-reduces) issued by the most recent hipeig_minres / hipeig_minres_block call of
- * this rank: a row-partitioned MINRES iteration costs two - the all-gather of the operand and ONE fused
- * all-reduce carrying <v,y>, <y,y> and the previous iteration's <x,x>.           */
+/* stats[0] = collectives (operand exchanges + all-reduces) issued by the most recent hipeig_minres / hipeig_minres_block call of
+ * this rank: a row-partitioned MINRES iteration costs two - the exchange of the operand, which also carries every rank's
+ * share of <y,y>, and ONE all-reduce carrying <v,y> and the previous iteration's <x,x>. */
 int hipeig_comm_stats(hipeig_ctx* ctx, int64_t stats[4]);
 /* Replica mode for work that is spread over ranks without partitioning the rows (FEAST: one contour
  * point per GPU, feast.py:186-201): partitioned = 0 keeps the communicator but switches the implicit
@@ -65,6 +65,26 @@ int hipeig_vec_allreduce(hipeig_ctx* ctx, double* v, int64_t n);
  * per rank; host barrier + device-to-device copies, sums in rank order).  Lets the multi-rank path
  * be run on a single GPU, where RCCL refuses two ranks on one device.  Every rank's thread must
  * make the same sequence of calls; a rank waiting 120 s for its peers fails instead of hanging. */
+/* ---- the operand exchange of a row-partitioned product (numpyVector.py:152: one H@x per MINRES iteration) ------------
+ * Two backends behind the same calls: 0 = RCCL's ncclAllGather (default), 1 = direct peer writes - every rank stores its
+ * slice into the gathered buffers of its peers over all xGMI links at once (csrc/comm_direct.hip).  The direct backend
+ * needs the peers' buffers mapped: hipeig_direct_alloc returns this rank's two hipIpc handles (128 bytes: gathered
+ * buffers, arrival flags; capacity in doubles per buffer, at least the gathered length of the largest operator), the host
+ * side all-gathers the records of all ranks in rank order (eigensolvers_amd.distributed) and hands them to
+ * hipeig_direct_attach; hipeig_comm_set_gather_backend then switches (every rank at the same point, nothing in flight).
+ * hipeig_comm_gather_info: info[0] backend, [1] attached, [2] capacity, [3] exchanges begun, [4] error word of the
+ * bounded waits (0 = none), [5] HIPEIG_GATHER_CHUNKS override (0 = automatic).                                        */
+int hipeig_direct_alloc(hipeig_ctx* ctx, int64_t capacity_doubles, void* handles128_out);
+int hipeig_direct_attach(hipeig_ctx* ctx, const void* all_handles /* nranks x 128 bytes */);
+int hipeig_comm_set_gather_backend(hipeig_ctx* ctx, int backend);
+int hipeig_comm_gather_info(hipeig_ctx* ctx, int64_t info[8]);
+/* measurement hooks: per-phase event times of the most recent partitioned product (ms; negative = phase absent):
+ * out[0] operand exchange, [1] sweep of the rank's own column windows (under the exchange), [2] sweep of the other
+ * windows incl. waits for later chunks, [3] whole product, [4] compute stream idle before the first chunk arrived;
+ * and the average time of `reps` back-to-back all-reduces of `count` doubles.                                          */
+int hipeig_phase_timing(hipeig_ctx* ctx, int on);
+int hipeig_phase_get(hipeig_ctx* ctx, double out[8]);
+int hipeig_comm_bench_allreduce(hipeig_ctx* ctx, int count, int reps, double* ms_each);
 int hipeig_loopback_group_create(int nranks, void** group_out);
 int hipeig_loopback_group_destroy(void* group);
 int hipeig_comm_init_loopback(hipeig_ctx* ctx, void* group, int rank);
@@ -157,6 +177,10 @@ int hipeig_csr_destroy(hipeig_ctx* ctx, hipeig_csr* A);
  * (1 CSR-vector, 2 CSR-stream, 3/4 column-window blocked with wave / workgroup units)
  * [5]=device bytes [6]=row blocks [7]=kernel launches (sweeps) per product of that variant */
 int hipeig_csr_info(hipeig_csr* A, int64_t info[8]);
+/* layout constants of the blocked copy the last product ran on: out[0] variant, [1] rows per row block, [2] window bits,
+ * [3] row blocks, [4] windows, [5] column splits, [6] workgroups per sweep launch, [7] threads per workgroup, [8] batch
+ * unroll, [9] chunks of the operand exchange, [10] rows per (rank, chunk) of the gathered layout (0: not partitioned) */
+int hipeig_csr_layout_info(hipeig_csr* A, int64_t out[12]);
 /* copy the device CSR (local rows) back to the host; pass NULL to skip an array          */
 int hipeig_csr_download(hipeig_ctx* ctx, hipeig_csr* A, int64_t* rowptr, int32_t* col,
                         double* val);

@@ -74,7 +74,7 @@ def test_forced_collectives_single_rank():
     assert r["cumIter"] == int(g["cumIter"]) and r["conv"]
     assert r["overlap_spmv_rel"] < 1e-14
     assert r["it4"] == r["it2"] and r["overlap_minres_rel"] < 1e-8
-    enq = 16 * -(-r["it2"] // 16)
-    assert r["coll"] == 2 * enq + enq // 16                  # one all-gather + one fused all-reduce per iteration
+    enq = 16 * -(-(r["it2"] + 1) // 16)                      # the stop of iteration K is seen in KC of iteration K + 1
+    assert r["coll"] == 2 * enq                              # one operand exchange (carrying <y,y>) + one all-reduce per iteration
     # the collectives run on ROCm's own RCCL, whatever else the process has loaded; no torch on the product path
     assert r["rccl"].startswith("/opt/rocm") and not r["torch_loaded"], r["rccl"]
