@@ -58,6 +58,17 @@ def parse():
     return ap.parse_args()
 
 
+def kernel_signature(layout):
+    """What a counter profile of the sweep is valid for: the sources of the sweep kernels and the layout constants of the
+    operator copy they ran on.  `profiles/pmc_current.json` carries the signature of the run it was collected from."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("spmv_device.h", "spmv.hip", "common.h"):
+        h.update(open(os.path.join(REPO, "eigensolvers_amd", "csrc", f), "rb").read())
+    h.update(json.dumps(layout, sort_keys=True).encode())
+    return h.hexdigest()[:16]
+
+
 def global_bytes(N, nnz):
     return nnz * 12 + (N + 1) * 4 + 8 * N + 8 * N
 
@@ -99,14 +110,26 @@ def main(result):
     except ea._lib.HipEigError:                      # launcher already narrowed the visible devices to one
         ctx = ea.HipContext(0)
     ea.HipContext._default = ctx
-    rccl_lib = None
+    # HIPEIG_COMM: "auto" (default) = RCCL communicator + the direct peer-write exchange next to it, the faster of the two
+    # is picked per operator by timing; "rccl" = RCCL only; "direct" = no RCCL at all (also what lets several ranks
+    # share ONE GPU, which RCCL refuses - a rehearsal of the whole multi-rank run on a single-GPU box)
+    comm_mode = os.environ.get("HIPEIG_COMM", "auto")
+    rccl_lib, direct_ok = None, False
     if world > 1 or force:
-        D.attach_rccl(ctx, rank, world)
-        buf = C.create_string_buffer(512)
-        ea._lib.call("hipeig_comm_library", buf, 512)
-        rccl_lib = buf.value.decode()
+        cap = D.gathered_capacity(a.n, world)
+        if comm_mode == "direct":
+            D.attach_direct(ctx, cap, rank, world)
+            direct_ok = True
+        else:
+            D.attach_rccl(ctx, rank, world)
+            buf = C.create_string_buffer(512)
+            ea._lib.call("hipeig_comm_library", buf, 512)
+            rccl_lib = buf.value.decode()
+            if comm_mode == "auto" and world > 1:
+                direct_ok = D.enable_direct_gather(ctx, cap, rank, world)
     group = D.DeviceGroup(ctx)
     barrier, allmax, allsum = group.barrier, group.allmax, group.allsum
+    n_ranks_seen = int(round(allsum(1.0)))           # one contribution per rank through the communicator itself
 
     N = a.n
     b, e = D.row_range(N, world, rank)
@@ -119,6 +142,14 @@ def main(result):
     nnz_total = int(allsum(float(H.nnz)))
     x = ea.HipVector(np.random.default_rng(100 + rank).standard_normal(e - b), ctx=ctx)
     y = ctx.alloc(e - b)
+    exchange = None
+    if world > 1:
+        if direct_ok and comm_mode == "auto":
+            exchange = D.choose_gather_backend(ctx, H, group, reps=5)      # RCCL vs peer writes, by timing 5 products of each
+        else:
+            gi = ctx.gather_info()
+            exchange = {"chosen": gi["backend"], "allreduce_chosen": gi["allreduce_backend"],
+                        "why": "HIPEIG_COMM=" + comm_mode if comm_mode != "auto" else "direct exchange unavailable (see stderr)"}
 
     for _ in range(a.warmup):
         H.apply_shifted(a.sigma, x._buf, y)
@@ -139,6 +170,24 @@ def main(result):
         singles.append(ctx.timer_stop())
     singles.sort()
     step_median, step_min = allmax(singles[len(singles) // 2]), allmax(singles[0])
+    # where a partitioned product spends its time (events on both streams, max over ranks of the per-rank averages) and
+    # what one small all-reduce of a MINRES iteration costs
+    phases = None
+    if world > 1 or force:
+        ctx.phase_timing(True)
+        acc = {}
+        for _ in range(10):
+            H.apply_shifted(a.sigma, x._buf, y)
+            for k, v in ctx.phase_times().items():
+                if v is not None:
+                    acc.setdefault(k, []).append(v)
+        ctx.phase_timing(False)
+        phases = {}
+        for k in ("gather_ms", "local_sweep_ms", "remote_sweep_ms", "product_ms", "idle_before_first_chunk_ms"):
+            v = allmax(sum(acc[k]) / len(acc[k]) if k in acc else -1.0)     # the same collective calls on every rank
+            phases[k] = round(v, 5) if v >= 0 else None
+        phases["allreduce_ms"] = round(allmax(ctx.allreduce_ms(2, 50)), 5)
+        phases["exchange_chunks"] = H.layout_info()["exchange_chunks"]
 
     # what a plain streaming kernel reaches on THIS device (confirm the nominal figure on the
     # box): out-of-place scale of 1e8 doubles, 0.8 GB read + 0.8 GB written per call, well past the Infinity Cache
@@ -162,35 +211,47 @@ def main(result):
                             "column-window-blocked(wave)": "spmv_tcoo_kernel",
                             "column-window-blocked(workgroup)": "spmv_tcoow_kernel",
                             "column-window-blocked(workgroup, fixed-point)": "spmv_tcoow_kernel"}[H.last_variant()]
+    signature = kernel_signature(H.layout_info())
+    traffic_note = None
     try:
         pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_current.json")))
-        if pmc["config"] == {"N": N, "nnz_row": a.nnz_row, "n_gpus": world}:
+        if pmc["config"] != {"N": N, "nnz_row": a.nnz_row, "n_gpus": world}:
+            traffic_note = "no counter pass for this configuration"
+        elif pmc.get("signature") != signature:
+            # the kernel or its layout changed since the counters were collected: do not report stale traffic
+            traffic_note = f"stale: counters were collected for kernel signature {pmc.get('signature')}, this run is {signature}"
+        else:
             traffic = pmc["kernels"].get(kname, {}).get("hbm_bytes_per_launch")
-    except Exception:
-        traffic = None
+    except Exception as exc:
+        traffic, traffic_note = None, f"profiles/pmc_current.json unreadable: {exc}"
     out = {
         "metric": "fp64 CSR SpMV GB/s (fused shift y = sigma*x - H x)", "value": round(value, 2), "unit": "GB/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(wall / a.steps * 1e3, 4),
+        "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(wall / a.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"random-sparse Hermitian CSR N={N} nnz/row~{a.nnz_row} (BASELINE metric config), "
                                f"row-partitioned over {world} GPU(s)",
-                   "N": N, "nnz": nnz_total, "nnz_per_row": round(nnz_total / N, 3), "sigma": a.sigma,
+                   "N": N, "nnz": nnz_total, "nnz_per_row": round(nnz_total / N, 3), "nnz_row_arg": a.nnz_row, "sigma": a.sigma,
                    "kernel_variant": ("auto:" if a.variant == 0 else "forced:") + H.last_variant(),
-                   "generator_seed": a.seed, "generate_s": round(t_gen, 2), "rccl_library": rccl_lib},
+                   "generator_seed": a.seed, "generate_s": round(t_gen, 2), "rccl_library": rccl_lib,
+                   "comm": comm_mode, "exchange": exchange, "layout": H.layout_info()},
         "roofline": {"bound": "hbm", "kernel": kname,
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4), "achievable_peak": HBM_ACHIEVABLE_GBS,
                      "measured_stream_GBs": round(copy_gbs, 1), "frac_of_measured_stream": round(achieved / copy_gbs, 4),
                      "traffic": traffic,
-                     "traffic_source": "profiles/pmc_current.json (separate rocprofv3 --pmc passes)" if traffic else None,
+                     "traffic_source": "profiles/pmc_current.json (separate rocprofv3 --pmc passes)" if traffic else traffic_note,
+                     "kernel_signature": signature,
                      "launches_per_step": nlaunch,
                      "algorithmic_bytes_per_launch": int(H.algorithmic_bytes() // nlaunch),
                      "avg_launch_ms": round(dev_ms / a.steps / nlaunch, 5),
                      "ms_per_step_device": round(dev_ms / a.steps, 5),
                      "single_step_ms_median": round(step_median, 5), "single_step_ms_min": round(step_min, 5)},
     }
+    if phases is not None:
+        out["phases"] = phases
 
     # ---- Lanczos iterations/s on the same operator (outside the timed SpMV region) ----
     if not a.no_lanczos:
@@ -241,6 +302,11 @@ def main(result):
                          "ms_per_block_iteration": round(1e3 * tb / max(itb), 4), "speedup": round(ts / tb, 3),
                          "max_rel_diff": float(max(ea.HipVector.linearCombination([Wb[j], Sb[j]], [1.0, -1.0]).norm() / Sb[j].norm()
                                                    for j in range(8)))}
+        # one MINRES iteration on the SAME N = 1e6 operator, device and (below) CPU restatement of the reference path
+        out["minres_n1e6"] = {"gpu_ms_per_iteration": round(1e3 * ts / max(1, sum(w.last_solve_stats["iterations"] for w in Sb)), 5),
+                              "iterations_per_solve": Sb[0].last_solve_stats["iterations"], "N": Nb, "nnz": int(Hb.nnz)}
+        Hb_host = Hb.to_scipy() if (rank == 0 and not a.no_cpu) else None
+        b_host = Qb[:, 0].copy()
         del Hb, Xb, Wb, Sb
 
     # ---- CPU baseline: scipy csr_matvec on a bounded row slab (rank 0, single GPU only) ----
@@ -268,15 +334,33 @@ def main(result):
         n_cpu = min(N, a.cpu_lanczos_n)
         Hc = gapped_csr_host(n_cpu, a.nnz_row, seed=a.seed)
         tl0 = time.perf_counter()
-        evc, Yc, stc = lanczos_ref.inexact_lanczos(Hc, RefVector(guess_vector(n_cpu, 1).copy(), {"linearSystemArgs": {
-            "linearSolver": "minres", "linearIter": 2000, "linear_tol": 1e-10}}), a.sigma, 3, 1, a.lanczos_econv)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):       # the oracle's "not converged" alert belongs in the JSON, not on stderr
+            evc, Yc, stc = lanczos_ref.inexact_lanczos(Hc, RefVector(guess_vector(n_cpu, 1).copy(), {"linearSystemArgs": {
+                "linearSolver": "minres", "linearIter": 2000, "linear_tol": 1e-10}}), a.sigma, 3, 1, a.lanczos_econv)
         tl0 = time.perf_counter() - tl0
         cpu_lanczos = {"N": n_cpu, "nnz_per_row": round(Hc.nnz / n_cpu, 2), "cum_iters": int(stc["cumIter"]),
                        "seconds": round(tl0, 2), "iters_per_s": round(stc["cumIter"] / tl0, 4), "ritz_value": float(evc[0]),
-                       "what": "oracle.lanczos_ref (NumPy/SciPy restatement of the reference path), one cycle L=3, "
-                               "minres rtol 1e-10, single-threaded csr_matvec"}
+                       "converged": bool(stc["isConverged"]),
+                       "what": "oracle.lanczos_ref (NumPy/SciPy restatement of the reference path), ONE cycle of L=3 (maxit = 1: "
+                               "a bounded sample, not run to convergence), minres rtol 1e-10, single-threaded csr_matvec"}
+        # (iii) the same inputs as the device: MINRES iterations of the oracle on the N = 1e6 config-#2 operator
+        # (numpyVector.py:163 -> scipy minres; here oracle.minres_ref, the restatement the parity tests use)
+        cpu_minres = None
+        if "minres_n1e6" in out and Hb_host is not None:
+            from oracle import minres_ref
+            nit = 8
+            t0c = time.perf_counter()
+            minres_ref.minres(lambda v: a.sigma * v - Hb_host @ v, b_host, rtol=1e-30, maxiter=nit)
+            t0c = time.perf_counter() - t0c
+            cpu_minres = {"cpu_ms_per_iteration": round(1e3 * t0c / nit, 3), "iterations_timed": nit, "cores": 1,
+                          "N": out["minres_n1e6"]["N"], "nnz": out["minres_n1e6"]["nnz"],
+                          "gpu_ms_per_iteration": out["minres_n1e6"]["gpu_ms_per_iteration"],
+                          "what": "oracle.minres_ref on the same N = 1e6, 32 nnz/row operator and right-hand side as the device solve"}
+            del Hb_host
         out["cpu_baseline"] = {"value": round(sb * reps / tc, 3), "unit": "GB/s", "cores": 1, "kind": "port",
-                               "lanczos": cpu_lanczos,
+                               "lanczos": cpu_lanczos, "minres_same_inputs": cpu_minres,
                                "sample": f"rows [0,{rows}) of the same operator ({slab.nnz} nnz), x of full length {N}, "
                                          f"{reps} reps of sigma*x - H@x via scipy.sparse csr_matvec (single-threaded), "
                                          f"{tc:.1f} s",

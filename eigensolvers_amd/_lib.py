@@ -38,6 +38,8 @@ SIGNATURES = {
     "hipeig_comm_stats": [_P, _I64P],
     "hipeig_comm_set_partitioned": [_P, C.c_int],
     "hipeig_vec_allreduce": [_P, _P, C.c_int64],
+    "hipeig_comm_init_direct": [_P, C.c_int, C.c_int],
+    "hipeig_comm_set_allreduce_backend": [_P, C.c_int],
     "hipeig_direct_alloc": [_P, _I64, _P],
     "hipeig_direct_attach": [_P, _P],
     "hipeig_comm_set_gather_backend": [_P, C.c_int],

@@ -198,8 +198,16 @@ static int loop_allreduce_f64(hipeig_ctx* c, double* buf, int count, hipStream_t
   return rc;
 }
 
+int hipeig_direct_allreduce(hipeig_ctx* c, double* buf, int64_t count, hipStream_t s);      // comm_direct.hip
+bool hipeig_direct_ready(const hipeig_ctx* c);
+
 static int coll_allgather(hipeig_ctx* c, const void* send, void* recv, size_t count, int type, hipStream_t s) {
   if (c->loop) return loop_allgather(c, send, recv, count * 8, s);      // both types used here are 8 bytes wide
+  if (!c->comm) {
+    hipeig_set_error("this exchange (a block operand, or an operator created before the direct exchange was attached) "
+                     "needs the RCCL communicator; the context has only the direct peer-write backend");
+    return 4;
+  }
   RCCL_CHECK(g_rccl.AllGather(send, recv, count, type, (ncclComm_t)c->comm, s));
   return 0;
 }
@@ -238,6 +246,22 @@ extern "C" int hipeig_comm_init(hipeig_ctx* c, int nranks, int rank, const void*
 
 int hipeig_direct_destroy(hipeig_ctx* c);
 
+// A communicator WITHOUT RCCL: rank / size only; every exchange then goes through the direct peer-write backend, which
+// must be attached (hipeig_direct_alloc / _attach) before the first operator is created.  What it cannot do is the
+// exchange of block operands (block products and lock-step block solves on a partitioned operator need RCCL).
+extern "C" int hipeig_comm_init_direct(hipeig_ctx* c, int nranks, int rank) {
+  HIPEIG_REQUIRE(nranks >= 1 && nranks <= HIPEIG_MAX_RANKS && rank >= 0 && rank < nranks, "bad rank/nranks");
+  HIPEIG_REQUIRE(c->comm == nullptr && c->loop == nullptr, "communicator already attached");
+  c->nranks = nranks;
+  c->rank = rank;
+  comm_flags_from_env(c, nranks);
+  c->gather_backend = 1;
+  c->allreduce_backend = 1;
+  free(c->row_counts);
+  c->row_counts = (int64_t*)calloc((size_t)nranks, sizeof(int64_t));
+  return 0;
+}
+
 extern "C" int hipeig_comm_destroy(hipeig_ctx* c) {
   if (c->direct) hipeig_direct_destroy(c);
   if (c->comm) {
@@ -269,6 +293,8 @@ extern "C" int hipeig_comm_stats(hipeig_ctx* c, int64_t stats[4]) {
 int hipeig_allreduce_sum(hipeig_ctx* c, double* d_buf, int count) {
   if (!c->collectives) return 0;
   if (c->loop) return loop_allreduce_f64(c, d_buf, count, c->stream);
+  if (!c->comm || (c->allreduce_backend == 1 && count <= 1024 && hipeig_direct_ready(c)))
+    return hipeig_direct_allreduce(c, d_buf, count, c->stream);
   RCCL_CHECK(g_rccl.AllReduce(d_buf, d_buf, (size_t)count, NCCL_FLOAT64, NCCL_SUM,
                               (ncclComm_t)c->comm, c->stream));
   return 0;
@@ -278,7 +304,7 @@ int hipeig_allreduce_sum(hipeig_ctx* c, double* d_buf, int count) {
 // attached but operators and vectors are whole on every rank, so reductions and products must NOT
 // go through the collectives; only hipeig_vec_allreduce does.  partitioned = 1 restores the default.
 extern "C" int hipeig_comm_set_partitioned(hipeig_ctx* c, int partitioned) {
-  HIPEIG_REQUIRE(c->comm != nullptr || c->loop != nullptr, "no communicator attached");
+  HIPEIG_REQUIRE(c->comm != nullptr || c->loop != nullptr || hipeig_direct_ready(c), "no communicator attached");
   if (partitioned) comm_flags_from_env(c, c->nranks);
   else { c->collectives = 0; c->overlap = 0; }
   return 0;
@@ -286,10 +312,11 @@ extern "C" int hipeig_comm_set_partitioned(hipeig_ctx* c, int partitioned) {
 
 // SUM over all ranks of a whole vector, in place (compute stream).
 extern "C" int hipeig_vec_allreduce(hipeig_ctx* c, double* v, int64_t n) {
-  HIPEIG_REQUIRE(c->comm != nullptr || c->loop != nullptr, "no communicator attached");
+  HIPEIG_REQUIRE(c->comm != nullptr || c->loop != nullptr || hipeig_direct_ready(c), "no communicator attached");
   HIPEIG_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "bad length");
   if (n == 0) return 0;
   if (c->loop) return loop_allreduce_f64(c, v, (int)n, c->stream);
+  if (!c->comm) return hipeig_direct_allreduce(c, v, n, c->stream);
   RCCL_CHECK(g_rccl.AllReduce(v, v, (size_t)n, NCCL_FLOAT64, NCCL_SUM, (ncclComm_t)c->comm, c->stream));
   return 0;
 }
@@ -337,11 +364,23 @@ int hipeig_comm_setup_rows(hipeig_ctx* c, int64_t nrows_local, GatherLayout* gl)
   int64_t* d = (int64_t*)c->d_scalars;
   HIPEIG_CHECK(hipStreamSynchronize(c->stream));            // the pinned staging word below is free
   int64_t* staged = (int64_t*)c->h_scalars;
-  staged[0] = nrows_local;
-  HIPEIG_CHECK(hipMemcpyAsync(d + c->rank, staged, sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-  if (coll_allgather(c, d + c->rank, d, 1, NCCL_INT64, c->stream)) return 4;
-  HIPEIG_CHECK(hipMemcpyAsync(c->row_counts, d, sizeof(int64_t) * c->nranks, hipMemcpyDeviceToHost, c->stream));
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  if (!c->comm && !c->loop) {
+    // direct-only communicator: the counts as a SUM of one-hot records of doubles (exact below 2^53)
+    HIPEIG_REQUIRE(hipeig_direct_ready(c), "attach the direct exchange before creating an operator");
+    double* hd = c->h_scalars;
+    for (int r = 0; r < c->nranks; ++r) hd[r] = (r == c->rank) ? (double)nrows_local : 0.0;
+    HIPEIG_CHECK(hipMemcpyAsync(c->d_scalars, hd, sizeof(double) * c->nranks, hipMemcpyHostToDevice, c->stream));
+    if (hipeig_direct_allreduce(c, c->d_scalars, c->nranks, c->stream)) return 4;
+    HIPEIG_CHECK(hipMemcpyAsync(hd, c->d_scalars, sizeof(double) * c->nranks, hipMemcpyDeviceToHost, c->stream));
+    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < c->nranks; ++r) c->row_counts[r] = (int64_t)hd[r];
+  } else {
+    staged[0] = nrows_local;
+    HIPEIG_CHECK(hipMemcpyAsync(d + c->rank, staged, sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    if (coll_allgather(c, d + c->rank, d, 1, NCCL_INT64, c->stream)) return 4;
+    HIPEIG_CHECK(hipMemcpyAsync(c->row_counts, d, sizeof(int64_t) * c->nranks, hipMemcpyDeviceToHost, c->stream));
+    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  }
   int64_t max_rows = 0;
   for (int r = 0; r < c->nranks; ++r) max_rows = c->row_counts[r] > max_rows ? c->row_counts[r] : max_rows;
   hipeig_gather_layout(c, max_rows, gl);

@@ -19,10 +19,17 @@
 // own sweep of exchange e + 1, which waited for MY push of e + 1, which my compute stream issued after my sweep of e.
 // So nobody overwrites a buffer that is still being read, provided every product waits for all chunks (it does).
 //
-// The all-reduce stays on RCCL: it is a few doubles and latency-bound either way.
+// The small all-reduces (MINRES scalars, dots) have a direct form too - mailboxes in the same fine-grained area, see the
+// end of this file - so a communicator can run without RCCL altogether (hipeig_comm_init_direct); whole-vector sums and
+// the exchange of block operands stay on RCCL.
 #include "common.h"
 
-#define DIRECT_FLAG_WORDS (2 * HIPEIG_GATHER_MAX_CHUNKS * HIPEIG_MAX_RANKS)
+#define DIRECT_MBOX_DOUBLES 1024                   // doubles one small all-reduce moves per rank
+#define DIRECT_GATHER_FLAGS (2 * HIPEIG_GATHER_MAX_CHUNKS * HIPEIG_MAX_RANKS)
+#define DIRECT_MBOX_FLAGS (2 * HIPEIG_MAX_RANKS)
+// fine-grained area of a rank, in 8-byte words: arrival flags of the exchange, flags of the mailboxes, the mailboxes
+#define DIRECT_MBOX_OFFSET (DIRECT_GATHER_FLAGS + DIRECT_MBOX_FLAGS)
+#define DIRECT_FLAG_WORDS (DIRECT_MBOX_OFFSET + 2 * HIPEIG_MAX_RANKS * DIRECT_MBOX_DOUBLES)
 #define DIRECT_WAIT_LIMIT_S 60
 
 struct DirectComm {
@@ -34,6 +41,7 @@ struct DirectComm {
   uint64_t* peer_flags[HIPEIG_MAX_RANKS];
   bool attached;
   uint64_t seq;                             // exchanges begun so far; the last one uses buffer seq & 1
+  uint64_t rseq;                            // small all-reduces begun so far (mailbox rseq & 1)
   unsigned* d_ticket;
   int* h_err;                               // mapped host word: a wait kernel gave up
   int* d_err;
@@ -112,7 +120,6 @@ int hipeig_direct_destroy(hipeig_ctx* c) {
 // Allocate this rank's two gathered buffers (capacity doubles each) and its flags; handles_out receives the two
 // 64-byte hipIpc handles (buffers, flags).  A previous allocation is released first (its peers must re-attach).
 extern "C" int hipeig_direct_alloc(hipeig_ctx* c, int64_t capacity_doubles, void* handles_out /* 128 bytes */) {
-  HIPEIG_REQUIRE(c->collectives || c->nranks >= 1, "no communicator");
   HIPEIG_REQUIRE(capacity_doubles > 0 && handles_out, "bad arguments");
   HIPEIG_REQUIRE(c->nranks <= HIPEIG_MAX_RANKS, "too many ranks for the direct exchange");
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is expected to be 64 bytes");
@@ -164,6 +171,8 @@ extern "C" int hipeig_direct_attach(hipeig_ctx* c, const void* all_handles) {
   }
   d->attached = true;
   d->seq = 0;
+  d->rseq = 0;
+  if (!c->comm && !c->loop) { c->gather_backend = 1; c->allreduce_backend = 1; }     // a direct-only communicator has nothing else
   return 0;
 }
 
@@ -172,9 +181,20 @@ extern "C" int hipeig_direct_attach(hipeig_ctx* c, const void* all_handles) {
 extern "C" int hipeig_comm_set_gather_backend(hipeig_ctx* c, int backend) {
   HIPEIG_REQUIRE(backend == 0 || backend == 1, "backend must be 0 (RCCL) or 1 (direct)");
   HIPEIG_REQUIRE(backend == 0 || (c->direct && c->direct->attached), "the direct exchange is not attached");
+  HIPEIG_REQUIRE(backend == 1 || c->comm || c->loop, "no RCCL communicator to switch to");
   HIPEIG_CHECK(hipStreamSynchronize(c->stream));
   HIPEIG_CHECK(hipStreamSynchronize(c->comm_stream));
   c->gather_backend = backend;
+  return 0;
+}
+
+// The same choice for the small all-reduces (<= 1024 doubles: MINRES scalars, dots, Gram blocks).
+extern "C" int hipeig_comm_set_allreduce_backend(hipeig_ctx* c, int backend) {
+  HIPEIG_REQUIRE(backend == 0 || backend == 1, "backend must be 0 (RCCL) or 1 (direct)");
+  HIPEIG_REQUIRE(backend == 0 || (c->direct && c->direct->attached), "the direct exchange is not attached");
+  HIPEIG_REQUIRE(backend == 1 || c->comm || c->loop, "no RCCL communicator to switch to");
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  c->allreduce_backend = backend;
   return 0;
 }
 
@@ -188,6 +208,7 @@ extern "C" int hipeig_comm_gather_info(hipeig_ctx* c, int64_t info[8]) {
     info[4] = *c->direct->h_err;
   }
   info[5] = c->gather_chunks;
+  info[6] = c->allreduce_backend;
   return 0;
 }
 
@@ -266,3 +287,82 @@ int hipeig_direct_wait_chunk(hipeig_ctx* c, const GatherLayout& gl, int chunk) {
   HIPEIG_CHECK(hipGetLastError());
   return 0;
 }
+
+// ---- small all-reduce through the peers' mailboxes -----------------------------------------------------------------
+// A SUM over the ranks of <= DIRECT_MBOX_DOUBLES doubles (MINRES: two per iteration) without RCCL: every rank stores its
+// values into mailbox [rseq & 1][this rank] of EVERY rank (its own included) and then flags them; a second one-workgroup
+// kernel waits (bounded) for the flags of all ranks and adds the mailboxes in rank order, so every rank obtains the
+// identical sum.  Two mailboxes suffice for the reason given at the top: a rank begins all-reduce s + 2 only after it
+// has finished s + 1, for which it needed every peer's s + 1, which each peer sent after finishing s.
+struct MboxTable {
+  double* box[HIPEIG_MAX_RANKS];           // mailbox of THIS rank inside rank p's area
+  uint64_t* flag[HIPEIG_MAX_RANKS];
+  int n;
+};
+
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+direct_mbox_push_kernel(const double* __restrict__ src, int count, MboxTable t, uint64_t seq) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    const double v = src[i];
+    for (int p = 0; p < t.n; ++p) __hip_atomic_store(t.box[p] + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if ((int)threadIdx.x < t.n) __hip_atomic_store(t.flag[threadIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+direct_mbox_sum_kernel(double* __restrict__ dst, int count, const double* boxes /* [ranks][DIRECT_MBOX_DOUBLES] */,
+                       const uint64_t* flags, int n, uint64_t seq, int64_t limit, int* err) {
+  __shared__ int sh_bad;
+  if (threadIdx.x == 0) sh_bad = 0;
+  __syncthreads();
+  if ((int)threadIdx.x < n) {
+    const int64_t t0 = wall_clock64();
+    while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      if (wall_clock64() - t0 > limit) {
+        __hip_atomic_store(err, 1 + (int)threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        sh_bad = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+  if (sh_bad) return;
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    double a = 0.0;
+    for (int r = 0; r < n; ++r) a += __hip_atomic_load(boxes + (size_t)r * DIRECT_MBOX_DOUBLES + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    dst[i] = a;
+  }
+}
+
+// In-place SUM all-reduce of `count` doubles on stream s (pieces of DIRECT_MBOX_DOUBLES).
+int hipeig_direct_allreduce(hipeig_ctx* c, double* buf, int64_t count, hipStream_t s) {
+  DirectComm* d = c->direct;
+  HIPEIG_REQUIRE(d && d->attached, "the direct exchange is not attached");
+  if (*d->h_err) {
+    hipeig_set_error("direct all-reduce: the contribution of rank %d did not arrive within the wait limit", *d->h_err - 1);
+    return 4;
+  }
+  for (int64_t o = 0; o < count; o += DIRECT_MBOX_DOUBLES) {
+    const int n = (int)((count - o < DIRECT_MBOX_DOUBLES) ? count - o : DIRECT_MBOX_DOUBLES);
+    const uint64_t e = ++d->rseq;
+    const int par = (int)(e & 1);
+    MboxTable t;
+    t.n = d->nranks;
+    for (int p = 0; p < d->nranks; ++p) {
+      double* area = reinterpret_cast<double*>(d->peer_flags[p] + DIRECT_MBOX_OFFSET);
+      t.box[p] = area + ((size_t)par * HIPEIG_MAX_RANKS + d->rank) * DIRECT_MBOX_DOUBLES;
+      t.flag[p] = d->peer_flags[p] + DIRECT_GATHER_FLAGS + (size_t)par * HIPEIG_MAX_RANKS + d->rank;
+    }
+    hipLaunchKernelGGL(direct_mbox_push_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, s, buf + o, n, t, e);
+    const double* mine = reinterpret_cast<const double*>(d->flags + DIRECT_MBOX_OFFSET) + (size_t)par * HIPEIG_MAX_RANKS * DIRECT_MBOX_DOUBLES;
+    hipLaunchKernelGGL(direct_mbox_sum_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, s, buf + o, n, mine,
+                       d->flags + DIRECT_GATHER_FLAGS + (size_t)par * HIPEIG_MAX_RANKS, d->nranks, e, d->wait_limit_ticks, d->d_err);
+  }
+  HIPEIG_CHECK(hipGetLastError());
+  return 0;
+}
+
+bool hipeig_direct_ready(const hipeig_ctx* c) { return c->direct && c->direct->attached; }

@@ -124,7 +124,8 @@ struct hipeig_ctx {
   hipEvent_t ev_ph[8];
   // direct all-gather backend (comm_direct.hip): peers' operand buffers and flags mapped through hipIpc
   struct DirectComm* direct;
-  int gather_backend;        // 0 = RCCL (or loopback), 1 = direct peer writes
+  int gather_backend;        // operand exchange: 0 = RCCL (or loopback), 1 = direct peer writes
+  int allreduce_backend;     // small (<= 1024 doubles) all-reduces: 0 = RCCL, 1 = the peers' mailboxes (comm_direct.hip)
 };
 
 struct hipeig_csr {
@@ -252,20 +253,41 @@ __device__ __forceinline__ double block_sum_partials(const double* __restrict__ 
 // capped at 2048 workgroups: the streaming reductions run on the same n/512-workgroup grids as the element-wise
 // kernels.  `counter` must be zero when the kernel starts and is zero again when it ends.
 // Usage inside a kernel (after every thread that holds a partial has stored it with store_partial):
-//   if (last_block_ticket(counter, tickets)) { t = sum_partials_agent(p, count, lds); if (threadIdx.x == 0) *total = t; ...;
+//   if (last_block_ticket(counters, tickets, my_slot)) { t = sum_partials_agent(p, count, lds); if (threadIdx.x == 0) *total = t; ...;
 //                                             release_ticket_counter(counter); }
 __device__ __forceinline__ void store_partial(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// True, uniformly over the workgroup, in the workgroup that takes the last of `tickets` tickets.  The barrier in front
-// makes the partial stores of ALL threads of this workgroup precede thread 0's release.
-__device__ __forceinline__ bool last_block_ticket(unsigned* counter, unsigned tickets) {
+// True, uniformly over the workgroup, in the workgroup that takes the last of `tickets` tickets (my_slot: this workgroup's
+// number among them).  The barrier in front makes the partial stores of ALL threads of this workgroup precede thread 0's.
+// Tickets are counted on two levels - workgroup b takes a ticket of group b / 64 and the workgroup that completes a
+// group takes one of the master counter - because ~10^4 atomic adds on ONE address serialise (measured: 7 ns each, 70 us
+// for the 9766 workgroups of an element-wise kernel at N = 1e7).  `counters`: 1 + ceil(tickets / 64) words, all zero
+// before the kernel and after it.
+//
+// The partials were stored with agent-scope atomic stores (written through to the point where all XCDs agree) and are
+// read back with agent-scope atomic loads, so what has to be ordered is only "my store has been performed before my
+// ticket is counted": a wait for the outstanding stores (the workgroup-scope release), not an agent-scope release,
+// which on this chip writes back and invalidates the XCD's whole L2 at the end of every workgroup (measured: +15 us per
+// kernel at N = 1e6).
+#define HIPEIG_TICKET_GROUP 64
+#define HIPEIG_TICKET_WORDS (1 + HIPEIG_WIDE_PARTIALS / HIPEIG_TICKET_GROUP + 7)
+__device__ __forceinline__ bool last_block_ticket(unsigned* counters, unsigned tickets, unsigned my_slot) {
   __shared__ int sh_last;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    sh_last = (t == tickets - 1u);
+    const unsigned ng = (tickets + HIPEIG_TICKET_GROUP - 1) / HIPEIG_TICKET_GROUP;
+    const unsigned g = my_slot / HIPEIG_TICKET_GROUP;
+    const unsigned gsize = (g == ng - 1) ? tickets - g * HIPEIG_TICKET_GROUP : HIPEIG_TICKET_GROUP;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    int last = 0;
+    if (__hip_atomic_fetch_add(counters + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
+      __hip_atomic_store(counters + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = __hip_atomic_fetch_add(counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    sh_last = last;
   }
   __syncthreads();
   const bool last = sh_last != 0;

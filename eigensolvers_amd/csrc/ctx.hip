@@ -33,8 +33,8 @@ extern "C" int hipeig_ctx_create(int device, hipeig_ctx** out) {
   HIPEIG_CHECK(hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming));
   for (int k = 0; k < HIPEIG_GATHER_MAX_CHUNKS; ++k) HIPEIG_CHECK(hipEventCreateWithFlags(&c->ev_chunk[k], hipEventDisableTiming));
   for (int k = 0; k < 8; ++k) HIPEIG_CHECK(hipEventCreate(&c->ev_ph[k]));
-  HIPEIG_CHECK(hipMalloc((void**)&c->d_counters, 64 * sizeof(unsigned)));
-  HIPEIG_CHECK(hipMemset(c->d_counters, 0, 64 * sizeof(unsigned)));
+  HIPEIG_CHECK(hipMalloc((void**)&c->d_counters, 4 * HIPEIG_TICKET_WORDS * sizeof(unsigned)));
+  HIPEIG_CHECK(hipMemset(c->d_counters, 0, 4 * HIPEIG_TICKET_WORDS * sizeof(unsigned)));
   c->partials_doubles = (size_t)HIPEIG_MAX_PARTIALS * HIPEIG_MAX_COLS * HIPEIG_MAX_COLS * 2;   // 8 MiB
   HIPEIG_CHECK(hipMalloc((void**)&c->d_partials, c->partials_doubles * sizeof(double)));
   c->scalars_doubles = 4096;

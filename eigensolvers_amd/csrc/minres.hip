@@ -141,7 +141,7 @@ minres_ka_kernel(CsrView A, TcooView T, const double* __restrict__ xg, MinresArg
     acc_xx = block_reduce_sum(acc_xx, red);
     if (threadIdx.x == 0) store_partial(kda.red.part + blockIdx.x, acc_xx);
   }
-  if (last_block_ticket(ra.counter, ra.tickets)) {
+  if (last_block_ticket(ra.counter, ra.tickets, (unsigned)(ra.part - ra.base) + blockIdx.x)) {
     const double vy = sum_partials_agent(ra.base, ra.count, red);
     const double xx = kda.do_kd ? sum_partials_agent(kda.red.base, kda.red.count, red) : 0.0;
     if (threadIdx.x == 0) {
@@ -189,7 +189,7 @@ minres_kc_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, M
   }
   acc = block_reduce_sum(acc, red);
   if (threadIdx.x == 0) store_partial(rc.part + blockIdx.x, acc);
-  if (last_block_ticket(rc.counter, rc.tickets)) {
+  if (last_block_ticket(rc.counter, rc.tickets, blockIdx.x)) {
     const double yy = sum_partials_agent(rc.base, rc.count, red);
     if (threadIdx.x == 0) {
       *rc.tot = yy;
@@ -241,7 +241,7 @@ minres_kd_kernel(int64_t n, MinresArgs a, const MinresState* __restrict__ Sin, M
   }
   acc = block_reduce_sum(acc, red);
   if (threadIdx.x == 0) store_partial(rd.part + blockIdx.x, acc);
-  if (last_block_ticket(rd.counter, rd.tickets)) {
+  if (last_block_ticket(rd.counter, rd.tickets, blockIdx.x)) {
     const double xx = sum_partials_agent(rd.base, rd.count, red);
     if (threadIdx.x == 0) *rd.tot = xx;
     release_ticket_counter(rd.counter);
@@ -330,15 +330,17 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
     HIPEIG_CHECK(hipFuncSetAttribute((const void*)minres_ka_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)HIPEIG_TCOO_LDS_MAX));
   const int gA = hipeig_spmv_grid(A, variant);
-  const int gE = grid_wide(n, 4);                            // element-wise kernels: their reductions finish in the last workgroup
+  int per_thread = 24;       // measured (tools/experiments/mr_grid_sweep.sh): 4 / 8 / 16 / 24 / 32 / 64 elements per thread -> 0.138 / 0.136 / 0.134 / 0.1335 / 0.135 / 0.140 ms per iteration at N = 1e6, 2.32 / 2.24 / 2.23 / 2.21 / 2.22 / 2.20 at N = 1e7: the fixed cost of a workgroup (state record, ticket), not the grid cap, is what these kernels feel
+  if (const char* e = getenv("HIPEIG_MR_PER_THREAD")) per_thread = atoi(e) > 0 ? atoi(e) : 24;     // tuning knob
+  const int gE = grid_wide(n, per_thread);                   // element-wise kernels: their reductions finish in the last workgroup
   // partial-sum areas (HIPEIG_WIDE_PARTIALS apart) and the totals their last workgroups leave
   double* pA = c->d_partials;
   double* pC = c->d_partials + HIPEIG_WIDE_PARTIALS;
   double* pD = c->d_partials + 2 * HIPEIG_WIDE_PARTIALS;
   double* tot = c->d_scalars + 3072;                         // [0] <v,y>, [1] <x,x> (one all-reduce record), [2] <y,y>, [4..5] end-of-solve flush
   unsigned* cntA = c->d_counters + 0;
-  unsigned* cntC = c->d_counters + 1;
-  unsigned* cntD = c->d_counters + 2;
+  unsigned* cntC = c->d_counters + HIPEIG_TICKET_WORDS;
+  unsigned* cntD = c->d_counters + 2 * HIPEIG_TICKET_WORDS;
   const bool dist = c->collectives != 0;
   MinresArgs a;
   a.sigma = sigma; a.sign = sign; a.rtol = rtol; a.maxiter = maxiter;

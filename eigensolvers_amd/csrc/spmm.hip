@@ -283,6 +283,12 @@ static int ensure_blk_ws(hipeig_ctx* c, size_t doubles) {
 extern "C" int hipeig_spmm(hipeig_ctx* c, hipeig_csr* A, int k, const double* const* X, double* const* Y) {
   HIPEIG_REQUIRE(k >= 1 && X && Y, "bad arguments");
   if (A->nrows == 0) return 0;
+  if (c->collectives && !c->comm && !c->loop) {
+    // a communicator without RCCL has no exchange for block operands: k products through the direct exchange instead
+    for (int j = 0; j < k; ++j)
+      if (hipeig_spmv(c, A, X[j], Y[j])) return 1;
+    return 0;
+  }
   // operand slice: a partitioned run hands over local slices; a row slab applied to full-length
   // operands (single process) gathers from the whole operand, so the block has ncols rows
   const int64_t nx = c->collectives ? A->nrows : A->ncols;

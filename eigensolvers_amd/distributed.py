@@ -339,6 +339,18 @@ def enable_direct_gather(ctx, capacity_doubles, rank=None, world=None):
     return False
 
 
+def attach_direct(ctx, capacity_doubles, rank=None, world=None):
+    """A communicator WITHOUT RCCL for ``ctx``: rank / size from the launcher's environment, the operand exchange and the
+    small all-reduces through peer writes (``enable_direct_gather``).  Raises when the peers cannot be mapped - there is
+    nothing to fall back to.  Block products on a partitioned operator need RCCL and are refused in this mode."""
+    if rank is None or world is None:
+        rank, world, _ = world_from_env()
+    ctx.attach_direct_only(world, rank)
+    if not enable_direct_gather(ctx, capacity_doubles, rank, world):
+        raise RuntimeError("the direct exchange could not be set up (see stderr) and this communicator has no RCCL")
+    return rank, world
+
+
 def choose_gather_backend(ctx, H, group, reps=5):
     """Time ``reps`` products of the partitioned operator ``H`` with each exchange backend, check that they give the same
     result (to rounding: the blocked sweep adds a row's terms in no fixed order), and switch every rank to the faster one (max over ranks decides, so all ranks agree).  The direct
@@ -364,8 +376,16 @@ def choose_gather_backend(ctx, H, group, reps=5):
     same = group.allmax(0.0 if same else 1.0) == 0.0
     pick = "direct" if (same and times["direct"] < times["rccl"]) else "rccl"
     ctx.set_gather_backend(pick)
+    # the small all-reduce of a MINRES iteration (two doubles), same choice by the same rule
+    ar = {}
+    for name in ("rccl", "direct"):
+        ctx.set_allreduce_backend(name)
+        ar[name] = group.allmax(ctx.allreduce_ms(2, 50))
+    pick_ar = "direct" if (same and ar["direct"] < ar["rccl"]) else "rccl"
+    ctx.set_allreduce_backend(pick_ar)
     return {"rccl_ms": round(times["rccl"], 4), "direct_ms": round(times["direct"], 4), "results_agree": same,
-            "chosen": pick, "reps": reps}
+            "chosen": pick, "reps": reps, "allreduce_rccl_ms": round(ar["rccl"], 4),
+            "allreduce_direct_ms": round(ar["direct"], 4), "allreduce_chosen": pick_ar}
 
 
 class DeviceGroup:

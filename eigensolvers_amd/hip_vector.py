@@ -41,6 +41,7 @@ class HipContext:
         self.handle = h
         self.device = int(device)
         self.nranks, self.rank = 1, 0
+        self.direct_only = False         # a communicator without RCCL (attach_direct_only): no exchange for block operands
         self._pool = {}
         self._finalizer = weakref.finalize(self, HipContext._destroy, h, self._pool)
 
@@ -91,15 +92,27 @@ class HipContext:
         buf = C.create_string_buffer(blob, len(blob))
         _lib.call("hipeig_direct_attach", self.handle, C.cast(buf, C.c_void_p))
 
+    def attach_direct_only(self, nranks, rank):
+        """A communicator without RCCL (rank / size only): every exchange goes through the direct peer-write backend,
+        which must be attached before the first operator is created (``distributed.attach_direct``)."""
+        _lib.call("hipeig_comm_init_direct", self.handle, int(nranks), int(rank))
+        self.nranks, self.rank = int(nranks), int(rank)
+        self.direct_only = True
+
     def set_gather_backend(self, name):
         code = {v: k for k, v in self.GATHER_BACKENDS.items()}[name]
         _lib.call("hipeig_comm_set_gather_backend", self.handle, code)
+
+    def set_allreduce_backend(self, name):
+        code = {v: k for k, v in self.GATHER_BACKENDS.items()}[name]
+        _lib.call("hipeig_comm_set_allreduce_backend", self.handle, code)
 
     def gather_info(self):
         info = (C.c_int64 * 8)()
         _lib.call("hipeig_comm_gather_info", self.handle, info)
         return {"backend": self.GATHER_BACKENDS[int(info[0])], "direct_attached": bool(info[1]), "capacity": int(info[2]),
-                "exchanges": int(info[3]), "wait_error": int(info[4]), "chunks_override": int(info[5])}
+                "exchanges": int(info[3]), "wait_error": int(info[4]), "chunks_override": int(info[5]),
+                "allreduce_backend": self.GATHER_BACKENDS[int(info[6])]}
 
     def phase_timing(self, on):
         _lib.call("hipeig_phase_timing", self.handle, 1 if on else 0)
@@ -618,7 +631,8 @@ class HipVector(AbstractVector):
         bs = list(bs)
         o = bs[0].options["linearSystemArgs"]
         if (o["linearSolver"] != "minres" or isinstance(sigma, complex) or np.iscomplexobj(sigma)
-                or x0 is not None or len(bs) < HipVector.BLOCK_SOLVE_MIN or not isinstance(H, HipCsrOperator)):
+                or x0 is not None or len(bs) < HipVector.BLOCK_SOLVE_MIN or not isinstance(H, HipCsrOperator)
+                or bs[0].ctx.direct_only):
             return [HipVector.solve(H, b, sigma, x0, opType, reverseGF) for b in bs]
         H.honour_reduction_option(bs[0].options)
         ctx, n = bs[0].ctx, bs[0]._buf.n

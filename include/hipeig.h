@@ -74,6 +74,8 @@ int hipeig_vec_allreduce(hipeig_ctx* ctx, double* v, int64_t n);
  * hipeig_direct_attach; hipeig_comm_set_gather_backend then switches (every rank at the same point, nothing in flight).
  * hipeig_comm_gather_info: info[0] backend, [1] attached, [2] capacity, [3] exchanges begun, [4] error word of the
  * bounded waits (0 = none), [5] HIPEIG_GATHER_CHUNKS override (0 = automatic).                                        */
+int hipeig_comm_init_direct(hipeig_ctx* ctx, int nranks, int rank);   /* rank / size without RCCL: every exchange direct */
+int hipeig_comm_set_allreduce_backend(hipeig_ctx* ctx, int backend);  /* small all-reduces: 0 RCCL, 1 the peers' mailboxes */
 int hipeig_direct_alloc(hipeig_ctx* ctx, int64_t capacity_doubles, void* handles128_out);
 int hipeig_direct_attach(hipeig_ctx* ctx, const void* all_handles /* nranks x 128 bytes */);
 int hipeig_comm_set_gather_backend(hipeig_ctx* ctx, int backend);

@@ -1,0 +1,92 @@
+"""The direct peer-write exchange (csrc/comm_direct.hip) between REAL processes: three ranks started by the package's own
+launcher share the one GPU of the test box, map each other's buffers through hipIpc handles that travel over the TCP
+group, and run row-partitioned products, dots, MINRES and block calls with no RCCL at all (`hipeig_comm_init_direct`).  What a
+multi-GPU node adds to this is only the xGMI hop under the same stores and flags."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %(repo)r)
+import eigensolvers_amd as ea
+from eigensolvers_amd import distributed as D
+from eigensolvers_amd.generators import guess_vector
+
+rank, world, _ = D.world_from_env()
+N = %(N)d
+ctx = ea.HipContext(0)                                   # every rank on the box's one GPU
+whole_ctx = ea.HipContext(0)                             # a second context without a communicator: the reference
+D.attach_direct(ctx, D.gathered_capacity(N, world), rank, world)
+assert "torch" not in sys.modules
+info0 = ctx.gather_info()
+b, e = D.row_range(N, world, rank)
+H = ea.HipCsrOperator.generate(N, 24, seed=21, row_begin=b, row_end=e, ctx=ctx)
+whole = ea.HipCsrOperator.generate(N, 24, seed=21, ctx=whole_ctx)
+whole.set_variant(2)
+x = np.random.default_rng(5).standard_normal(N)
+y_ref = ea.HipVector(x, ctx=whole_ctx).applyOp(whole).array
+out = {"rank": rank, "world": world, "backend": info0["backend"], "allreduce_backend": info0["allreduce_backend"]}
+X = ea.HipVector(x[b:e], ctx=ctx)
+for variant in (2, 4):
+    H.set_variant(variant)
+    errs = []
+    for rep in range(6):                                 # both buffers of the double-buffered exchange, several times
+        y = X.applyOp(H).array
+        errs.append(float(np.max(np.abs(y - y_ref[b:e])) / np.max(np.abs(y_ref))))
+    out["spmv%%d" %% variant] = max(errs)
+out["layout"] = H.layout_info()
+out["dot"] = X.vdot(X)
+out["dot_ref"] = float(np.dot(x, x))
+opts = {"linearSystemArgs": {"linearSolver": "minres", "linearIter": 2000, "linear_tol": 1e-10}}
+bf = guess_vector(N, 4) / np.linalg.norm(guess_vector(N, 4))
+w_ref = ea.HipVector.solve(whole, ea.HipVector(bf.copy(), dict(opts), ctx=whole_ctx), 0.02)
+w = ea.HipVector.solve(H, ea.HipVector(bf[b:e].copy(), dict(opts), ctx=ctx), 0.02)
+out.update(it=w.last_solve_stats["iterations"], it_ref=w_ref.last_solve_stats["iterations"],
+           istop=w.last_solve_stats["istop"], coll=w.last_solve_stats["collectives"],
+           werr=float(np.linalg.norm(w.array - w_ref.array[b:e]) / np.linalg.norm(w_ref.array)))
+# block operands have no direct exchange: the block product runs as k single products, solveBlock one by one
+Yb = H.apply_block([X._buf, X._buf])
+out["block"] = max(float(np.max(np.abs(ea.HipVector(yb).array - y_ref[b:e])) / np.max(np.abs(y_ref))) for yb in Yb)
+Wb = ea.HipVector.solveBlock(H, [ea.HipVector(bf[b:e].copy(), dict(opts), ctx=ctx) for _ in range(3)], 0.02)
+out["block_it"] = [wb.last_solve_stats["iterations"] for wb in Wb]
+g = D.DeviceGroup(ctx)
+g.barrier()
+out["allmax"] = g.allmax(float(rank))
+info = ctx.gather_info()
+out.update(exchanges=info["exchanges"], wait_error=info["wait_error"])
+with open(os.path.join(%(outdir)r, "rank%%d.json" %% rank), "w") as f:
+    json.dump(out, f)
+D.tcp_group().barrier()                                  # nobody unmaps a buffer a peer may still write to
+'''
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("chunks", [1, 2])
+def test_three_processes_exchange_by_peer_writes(tmp_path, chunks):
+    from eigensolvers_amd.distributed import launch_local
+    N, P = 250_001, 3
+    prog = tmp_path / "child.py"
+    prog.write_text(CHILD % {"repo": REPO, "N": N, "outdir": str(tmp_path)})
+    rc, out = launch_local([str(prog)], P, timeout=600,
+                           env_extra={"HIPEIG_GATHER_CHUNKS": str(chunks), "HIPEIG_TCOOW_WBITS": "13", "HIPEIG_DIRECT_WAIT_S": "20"})
+    assert rc == 0, out[-2000:]
+    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(P)]
+    for r, o in enumerate(res):
+        assert (o["rank"], o["world"]) == (r, P) and o["backend"] == "direct" and o["allreduce_backend"] == "direct"
+        assert o["layout"]["exchange_chunks"] == chunks
+        assert o["spmv2"] < 1e-14 and o["spmv4"] < 1e-14
+        assert abs(o["dot"] - o["dot_ref"]) < 1e-10 * o["dot_ref"] and o["dot"] == res[0]["dot"]     # identical on every rank
+        assert o["it"] == res[0]["it"] and abs(o["it"] - o["it_ref"]) <= 2 and o["istop"] in (1, 2)
+        assert o["coll"] == 2 * 16 * -(-(o["it"] + 1) // 16)
+        assert o["werr"] < 1e-8
+        assert o["block"] < 1e-14 and o["block_it"] == [o["it"]] * 3
+        assert o["allmax"] == float(P - 1) and o["wait_error"] == 0 and o["exchanges"] > 12

@@ -46,9 +46,24 @@ def single_1e6(hip, op1e6):
     return ev, Y, st
 
 
+def _golden_json(name):
+    import json
+    import os
+    from conftest import GOLDEN
+    path = os.path.join(GOLDEN, name)
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
 def test_config2_single_vector_lanczos_at_1e6(hip, op1e6, single_1e6):
     ev, Y, st = single_1e6
     assert st["isConverged"] and st["residual"] <= 1e-12 and 2 <= st["cumIter"] <= 4 * 7
+    # the REAL reference on the same inputs (tests/golden/make_golden_r3.py: inexact_Lanczos.py:229-443 through
+    # numpyVector.py:147-178 with scipy minres, 913 s of one CPU core): north-star tolerance, same iteration count
+    g = _golden_json("config2_n1e6.json")
+    assert g is not None and (g["N"], g["nnz_row"], g["seed"], g["L"], g["maxit"], g["eConv"], g["linear_tol"]) == \
+        (1_000_000, 32, 7, 8, 4, 1e-12, 1e-10) and g["nnz"] == op1e6.nnz
+    assert abs(ev[0] - g["ev0"]) <= 1e-10 * abs(g["ev0"]), (ev[0], g["ev0"])
+    assert st["cumIter"] == g["cumIter"] and st["isConverged"] == g["isConverged"]
     r = hip.true_residual_norms(op1e6, ev, Y, 1)[0]
     assert r < 1e-6                                         # => an eigenvalue within r^2 / gap = 4e-11 of theta
     assert r * r / GAP < 1e-10 * abs(ev[0])

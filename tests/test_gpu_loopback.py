@@ -183,7 +183,8 @@ def test_chunked_exchange_layout_on_three_ranks(hip, chunks, monkeypatch):
             assert np.max(np.abs(yb - yb_ref[j])) <= 1e-13 * np.max(np.abs(yb_ref[j]))
 
 
-def test_partitioned_minres_on_a_near_eigenvector(hip):
+@pytest.mark.parametrize("rtol", [1e-6, 1e-10])
+def test_partitioned_minres_on_a_near_eigenvector(hip, rtol):
     """a right-hand side that is an eigenvector + 1e-9 noise (what restarts and converged Ritz vectors
     hand to the inner solve).  Round 2's partitioned path took beta^2 as <y,y> - alfa^2, which cancels here (wrong by
     50 % at 1e-8, clamped to 0 -> NaN at 1e-9); now every rank's share of the directly reduced <y,y> rides on the
@@ -200,12 +201,12 @@ def test_partitioned_minres_on_a_near_eigenvector(hip):
     for eps in (1e-8, 1e-9, 1e-10):
         b = vec[:, 0] + eps * rng.standard_normal(N)
         rhs.append(b / np.linalg.norm(b))
-    opts = {"linearSystemArgs": {"linearSolver": "minres", "linearIter": 500, "linear_tol": 1e-10}}
+    opts = {"linearSystemArgs": {"linearSolver": "minres", "linearIter": 500, "linear_tol": rtol}}
     single = hip.HipCsrOperator.from_scipy(Hh)
     ref = []
     for b in rhs:
         w = hip.HipVector.solve(single, hip.HipVector(b.copy(), dict(opts)), sigma)
-        xo, info, itn, istop = minres_ref.minres(lambda v: sigma * v - Hh @ v, b, rtol=1e-10, maxiter=500)
+        xo, info, itn, istop = minres_ref.minres(lambda v: sigma * v - Hh @ v, b, rtol=rtol, maxiter=500)
         assert (w.last_solve_stats["iterations"], w.last_solve_stats["istop"]) == (itn, istop) and info == 0
         ref.append((itn, istop, w.array))
     grp = LoopbackGroup(P)
@@ -226,13 +227,14 @@ def test_partitioned_minres_on_a_near_eigenvector(hip):
     finally:
         grp.close()
     for j, (itn, istop, w_ref) in enumerate(ref):
-        assert itn <= 6                                                  # the solve is over in a handful of iterations
+        if rtol == 1e-6:
+            assert itn <= 3                                              # over in a step or two: beta_2 is ~1e-8 of alfa_1 here
         for which in (0, 1):
             got = [r[which][j] for r in res]
             assert all((g[0], g[1]) == (itn, istop) for g in got), (j, which, [(g[0], g[1]) for g in got], (itn, istop))
             w = np.concatenate([g[2] for g in got])
             assert np.all(np.isfinite(w))
-            assert np.linalg.norm(w - w_ref) <= 1e-9 * np.linalg.norm(w_ref)
+            assert np.linalg.norm(w - w_ref) <= max(1e-9, 10 * rtol) * np.linalg.norm(w_ref)
 
 
 @pytest.mark.parametrize("P", [3, 5])

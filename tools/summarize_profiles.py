@@ -50,6 +50,19 @@ def main():
                 e["l2_hit_rate"] = h / (h + m) if h + m else None
         summary[k] = e
     json.dump(summary, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
+    # the bench line of the FETCH pass names the kernel signature and configuration the counters belong to: with it the
+    # summary becomes profiles/pmc_current.json, which bench.py refuses to quote for any other kernel / layout
+    log = pf.rstrip("/") + ".log"
+    if os.path.exists(log):
+        lines = [ln for ln in open(log).read().splitlines() if ln.startswith("{")]
+        if lines:
+            b = json.loads(lines[-1])
+            cur = {"config": {"N": b["config"]["N"], "nnz_row": int(round(b["config"]["nnz_per_row"])) - 1, "n_gpus": b["n_gpus"]},
+                   "signature": b["roofline"].get("kernel_signature"), "layout": b["config"].get("layout"),
+                   "kernels": summary, "source": f"tools/profile_round.sh {tag} (separate rocprofv3 --pmc passes: FETCH_SIZE, WRITE_SIZE, "
+                                                 "TCC_HIT/MISS; reads = 2 x FETCH_SIZE on gfx950)"}
+            json.dump(cur, open("profiles/pmc_current.json", "w"), indent=1, sort_keys=True)
+            print("profiles/pmc_current.json <-", cur["config"], cur["signature"])
     print(json.dumps({k: v for k, v in summary.items() if "spmv" in k or "minres" in k}, indent=1))
 
 
