@@ -72,6 +72,10 @@ SIGNATURES = {
     "hipeig_pair_mgs_project": [_P, _I64, C.c_int, _PP, _PP, _P, _P, _DP],
     "hipeig_arnoldi_step": [_P, _I64, C.c_int, _PP, _P, _DP],
     "hipeig_pair_arnoldi_step": [_P, _I64, C.c_int, _PP, _PP, _P, _P, _DP],
+    "hipeig_arnoldi_step_p": [_P, _I64, C.c_int, _PP, _P, _DP, C.c_int],
+    "hipeig_pair_arnoldi_step_begin": [_P, _I64, C.c_int, _PP, _PP, _P, _P, C.c_int, C.c_int],
+    "hipeig_arnoldi_step_end": [_P, C.c_int, C.c_int, _DP],
+    "hipeig_pair_arnoldi_step_p": [_P, _I64, C.c_int, _PP, _PP, _P, _P, _DP, C.c_int],
     "hipeig_csr_create": [_P, _I64, _I64, _I64, _I64P, _I32P, _DP, _PP],
     "hipeig_csr_generate": [_P, _I64, _I64, _I64, C.c_int, C.c_uint64, _D, C.c_uint32, _DP, C.c_int, _PP],
     "hipeig_csr_destroy": [_P, _P],
@@ -86,6 +90,7 @@ SIGNATURES = {
     "hipeig_spmv_shift_pair": [_P, _P, _D, _D, _D, _P, _P, _P, _P],
     "hipeig_csr_pair_info": [_P, _I64P],
     "hipeig_spmm": [_P, _P, C.c_int, _PP, _PP],
+    "hipeig_spmm_shift_pairs": [_P, _P, C.c_int, _D, _D, _D, _PP, _PP, _PP, _PP],
     "hipeig_minres": [_P, _P, _D, _D, _P, _P, _D, C.c_int, _IP, _DP],
     "hipeig_minres_x0": [_P, _P, _D, _D, _P, _P, _P, _D, C.c_int, _IP, _DP],
     "hipeig_dense_solve_small": [_P, _P, _D, _D, _D, _P, _P, _P, _P, _IP],

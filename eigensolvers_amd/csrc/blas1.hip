@@ -1066,6 +1066,236 @@ static int arnoldi_fused(hipeig_ctx* c, int64_t n, int m, const double* const* V
   return 0;
 }
 
+// ---- several columns per pass (option; hipeig_arnoldi_step_p) ------------------------------------------------------
+// The sweep above reads w once per column.  Here a pass applies the updates of a whole BLOCK of P = 4 columns and, in
+// the same pass, forms everything the next block needs: its dot products with the updated w AND the Gram entries
+// G_kl = <V_k, V_l> (l < k) of its own columns, from which the coefficients of the sequential sweep follow exactly,
+//   h_0 = <V_0, w>,   h_k = <V_k, w - sum_{l<k} h_l V_l> = <V_k, w> - sum_{l<k} h_l G_kl .
+// Algebraically this IS the modified Gram-Schmidt sweep of scipy's _fgmres, column after column; it differs in
+// rounding (the G terms are accumulated sums instead of being folded into w element by element), which is why it is an
+// option and the one-column form stays the default (iteration-count parity with scipy.sparse.linalg.gcrotmk).
+// Traffic per column: (2P + 2) / P = 2.5 vector streams instead of 4, and a launch per FOUR columns.
+// All sums finish in the kernel's last workgroup (common.h), so the next launch's prologue reads ~20 doubles.
+#ifndef ARN_P
+#define ARN_P 4
+#endif
+struct ArnBlockCols { const double* re[ARN_P]; const double* im[ARN_P]; };
+template <bool PAIR> struct ArnBlockShape {
+  static constexpr int W = PAIR ? 2 : 1;
+  static constexpr int NG = W * ARN_P;                         // dot products of a block with w
+  static constexpr int NGRAM = W * ARN_P * (ARN_P - 1) / 2;    // lower triangle of the block's Gram matrix
+  static constexpr int NV = NG + NGRAM + 1;                    // + one sum of squares
+};
+
+template <bool PAIR>
+__global__ void __launch_bounds__(HIPEIG_BLOCK)
+arnoldi_block_kernel(int64_t n, const double* __restrict__ tin, int nb_in, ArnBlockCols cur, int nb_next, ArnBlockCols nxt,
+                     int want_ss, double* __restrict__ wre, double* __restrict__ wim, double* __restrict__ coef_out,
+                     double* __restrict__ partials, unsigned* counters, double* __restrict__ tout, double* __restrict__ ss_out) {
+  using Sh = ArnBlockShape<PAIR>;
+  constexpr int W = Sh::W, P = ARN_P;
+  __shared__ double lds[4];
+  // coefficients of the block being applied, from the sums the previous launch left (identical in every thread)
+  double hr[P], hi[P];
+#pragma unroll
+  for (int k = 0; k < P; ++k) { hr[k] = 0.0; hi[k] = 0.0; }
+  if (nb_in > 0) {
+    int gi = Sh::NG;                                           // Gram entries follow the dots: (k, l) for k = 1.., l < k
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      if (k < nb_in) {
+        double cr = tin[W * k], ci = PAIR ? tin[W * k + 1] : 0.0;
+#pragma unroll
+        for (int l = 0; l < k; ++l) {
+          const double gr = tin[gi + W * l], gim = PAIR ? tin[gi + W * l + 1] : 0.0;
+          cr -= hr[l] * gr - hi[l] * gim;                      // h_l * G_kl
+          if (PAIR) ci -= hr[l] * gim + hi[l] * gr;
+        }
+        hr[k] = cr; hi[k] = ci;
+      }
+      gi += W * k;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      for (int k = 0; k < nb_in; ++k) { coef_out[W * k] = hr[k]; if (PAIR) coef_out[W * k + 1] = hi[k]; }
+  }
+  double acc[Sh::NV];
+#pragma unroll
+  for (int v = 0; v < Sh::NV; ++v) acc[v] = 0.0;
+  const int64_t n2 = n >> 1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    double2 cp[P], cq[P], np_[P], nq[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      if (k < nb_in) { cp[k] = arn_ld(cur.re[k], i, true); if (PAIR) cq[k] = arn_ld(cur.im[k], i, true); }
+      if (k < nb_next) { np_[k] = arn_ld(nxt.re[k], i, false); if (PAIR) nq[k] = arn_ld(nxt.im[k], i, false); }
+    }
+    double2 x = arn_ld(wre, i, false), y = PAIR ? arn_ld(wim, i, false) : make_double2(0.0, 0.0);
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      if (k < nb_in) {
+        if (PAIR) {
+          x.x -= hr[k] * cp[k].x - hi[k] * cq[k].x; y.x -= hr[k] * cq[k].x + hi[k] * cp[k].x;      // w -= h * v
+          x.y -= hr[k] * cp[k].y - hi[k] * cq[k].y; y.y -= hr[k] * cq[k].y + hi[k] * cp[k].y;
+        } else {
+          x.x = fma(-hr[k], cp[k].x, x.x); x.y = fma(-hr[k], cp[k].y, x.y);
+        }
+      }
+    }
+    if (nb_in > 0) {
+      reinterpret_cast<double2*>(wre)[i] = x;
+      if (PAIR) reinterpret_cast<double2*>(wim)[i] = y;
+    }
+    int gi = Sh::NG;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      if (k < nb_next) {
+        // conj(v_k) . w
+        acc[W * k] = fma(np_[k].x, x.x, acc[W * k]); acc[W * k] = fma(np_[k].y, x.y, acc[W * k]);
+        if (PAIR) {
+          acc[W * k] = fma(nq[k].x, y.x, acc[W * k]); acc[W * k] = fma(nq[k].y, y.y, acc[W * k]);
+          acc[W * k + 1] = fma(np_[k].x, y.x, acc[W * k + 1]); acc[W * k + 1] = fma(-nq[k].x, x.x, acc[W * k + 1]);
+          acc[W * k + 1] = fma(np_[k].y, y.y, acc[W * k + 1]); acc[W * k + 1] = fma(-nq[k].y, x.y, acc[W * k + 1]);
+        }
+#pragma unroll
+        for (int l = 0; l < k; ++l) {                          // conj(v_k) . v_l
+          double& gr = acc[gi + W * l];
+          gr = fma(np_[k].x, np_[l].x, gr); gr = fma(np_[k].y, np_[l].y, gr);
+          if (PAIR) {
+            gr = fma(nq[k].x, nq[l].x, gr); gr = fma(nq[k].y, nq[l].y, gr);
+            double& gm = acc[gi + W * l + 1];
+            gm = fma(np_[k].x, nq[l].x, gm); gm = fma(-nq[k].x, np_[l].x, gm);
+            gm = fma(np_[k].y, nq[l].y, gm); gm = fma(-nq[k].y, np_[l].y, gm);
+          }
+        }
+      }
+      gi += W * k;
+    }
+    if (want_ss) {
+      double& ss = acc[Sh::NV - 1];
+      ss = fma(x.x, x.x, ss); ss = fma(x.y, x.y, ss);
+      if (PAIR) { ss = fma(y.x, y.x, ss); ss = fma(y.y, y.y, ss); }
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {         // odd length: the last element (loops unrolled: acc stays in registers)
+    const int64_t i = n - 1;
+    double x = wre[i], y = PAIR ? wim[i] : 0.0;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      if (k < nb_in) {
+        const double p = cur.re[k][i], q = PAIR ? cur.im[k][i] : 0.0;
+        const double nx = x - (hr[k] * p - hi[k] * q);
+        y = y - (hr[k] * q + hi[k] * p);
+        x = nx;
+      }
+    }
+    if (nb_in > 0) { wre[i] = x; if (PAIR) wim[i] = y; }
+    double pn[P], qn[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) { pn[k] = k < nb_next ? nxt.re[k][i] : 0.0; qn[k] = (PAIR && k < nb_next) ? nxt.im[k][i] : 0.0; }
+    int gi = Sh::NG;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      if (k < nb_next) {
+        acc[W * k] = fma(pn[k], x, acc[W * k]);
+        if (PAIR) { acc[W * k] = fma(qn[k], y, acc[W * k]); acc[W * k + 1] = fma(pn[k], y, acc[W * k + 1]); acc[W * k + 1] = fma(-qn[k], x, acc[W * k + 1]); }
+#pragma unroll
+        for (int l = 0; l < k; ++l) {
+          acc[gi + W * l] = fma(pn[k], pn[l], acc[gi + W * l]);
+          if (PAIR) {
+            acc[gi + W * l] = fma(qn[k], qn[l], acc[gi + W * l]);
+            acc[gi + W * l + 1] = fma(pn[k], qn[l], acc[gi + W * l + 1]); acc[gi + W * l + 1] = fma(-qn[k], pn[l], acc[gi + W * l + 1]);
+          }
+        }
+      }
+      gi += W * k;
+    }
+    if (want_ss) { acc[Sh::NV - 1] = fma(x, x, acc[Sh::NV - 1]); if (PAIR) acc[Sh::NV - 1] = fma(y, y, acc[Sh::NV - 1]); }
+  }
+  // all NV sums of the workgroup through ONE LDS stage (wave shuffles, one barrier, thread v adds the four wave sums)
+  const int G = gridDim.x;
+  __shared__ double red[Sh::NV][HIPEIG_BLOCK / 64];
+  {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int v = 0; v < Sh::NV; ++v) {
+      const double r = wave_reduce_sum(acc[v]);
+      if (lane == 0) red[v][wid] = r;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < Sh::NV) {
+      double t = red[threadIdx.x][0];
+      for (int w = 1; w < HIPEIG_BLOCK / 64; ++w) t += red[threadIdx.x][w];
+      store_partial(partials + (size_t)threadIdx.x * G + blockIdx.x, t);
+    }
+  }
+  if (last_block_ticket(counters, (unsigned)G, blockIdx.x)) {
+    // the NV totals side by side: 8 lanes per value (8 x 21 = 168 <= 256 threads), lane k adds the partials k, k + 8, ...
+    // in ascending order and the 8 lane sums are folded in a fixed tree
+    const int v = threadIdx.x >> 3, k = threadIdx.x & 7;
+    double a = 0.0;
+    if (v < Sh::NV)
+      for (int i = k; i < G; i += 8) a += __hip_atomic_load(partials + (size_t)v * G + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 1, 64);
+    if (v < Sh::NV && k == 0) {
+      tout[v] = a;
+      if (v == Sh::NV - 1 && ss_out) *ss_out = a;
+    }
+    release_ticket_counter(counters);
+  }
+}
+
+template <bool PAIR>
+static int arnoldi_blocked(hipeig_ctx* c, int64_t n, int m, const double* const* Vre, const double* const* Vim,
+                           double* wre, double* wim, double* dres) {
+  using Sh = ArnBlockShape<PAIR>;
+  constexpr int W = Sh::W;
+  // One workgroup per CU, whatever the length (measured, tools/experiments/arnoldi_bench.py, 28 complex columns: N = 1e7
+  // 145 / 113 / 98 / 89 / 82 us per column at 4883 / 2441 / 1220 / 610 / 244 workgroups, N = 1e6 15.6 / 12.8 at 488 / 244; the
+  // sequential sweep: 116 / 13.9).  A pass reads 18 streams at once; with one workgroup per CU the whole chip walks through
+  // each of them as one narrow front.
+  int g = c->num_cu;
+  if (const char* e = getenv("HIPEIG_ARNOLDI_PER_THREAD")) g = grid_wide(n, atoi(e) > 0 ? atoi(e) : 16);      // tuning knob (elements per thread)
+  if ((int64_t)g * HIPEIG_BLOCK * 2 > n) g = (int)((n / 2 + HIPEIG_BLOCK - 1) / HIPEIG_BLOCK);
+  if (g < 1) g = 1;
+  if (g > 8192) g = 8192;                                      // Sh::NV partial areas of g doubles each
+  double* P0 = c->d_partials;
+  double* tot = c->d_scalars + 3200;                           // two total records of <= 32 doubles, used alternately
+  unsigned* cnt = c->d_counters + 3 * HIPEIG_TICKET_WORDS;
+  auto cols = [&](int b0, ArnBlockCols* out) -> int {
+    int nb = m - b0;
+    if (nb > ARN_P) nb = ARN_P;
+    if (nb < 0) nb = 0;
+    for (int k = 0; k < ARN_P; ++k) {
+      out->re[k] = k < nb ? Vre[b0 + k] : nullptr;
+      out->im[k] = (PAIR && k < nb) ? Vim[b0 + k] : nullptr;
+    }
+    return nb;
+  };
+  ArnBlockCols none, cur, nxt;
+  cols(m, &none);
+  int nb_next = cols(0, &nxt);
+  // first pass: ||w||^2 before and everything block 0 needs (no update); with m == 0 it is also ||w||^2 after
+  hipLaunchKernelGGL((arnoldi_block_kernel<PAIR>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, (const double*)nullptr, 0, none,
+                     nb_next, nxt, 1, wre, wim, (double*)nullptr, P0, cnt, tot, dres);
+  int flip = 0;
+  for (int b0 = 0; b0 < m; b0 += ARN_P) {
+    cur = nxt;
+    const int nb_in = nb_next;
+    nb_next = cols(b0 + ARN_P, &nxt);
+    const int last = (nb_next == 0);
+    hipLaunchKernelGGL((arnoldi_block_kernel<PAIR>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, tot + 32 * flip, nb_in, cur,
+                       nb_next, nxt, last, wre, wim, dres + 1 + W * b0, P0, cnt, tot + 32 * (flip ^ 1),
+                       last ? dres + 1 + W * m : (double*)nullptr);
+    flip ^= 1;
+  }
+  if (m == 0)
+    HIPEIG_CHECK(hipMemcpyAsync(dres + 1, dres, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(scale_by_inv_norm_kernel, dim3(grid_stream(n)), dim3(HIPEIG_BLOCK), 0, c->stream, n, dres + 1 + W * m, wre, wim);
+  HIPEIG_CHECK(hipGetLastError());
+  return 0;
+}
+
 static int arnoldi_sumsq(hipeig_ctx* c, int64_t n, const double* a, const double* b, int g, double* dst) {
   hipLaunchKernelGGL(sumsq_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, a, b, c->d_partials);
   hipLaunchKernelGGL(mgsp_reduce_kernel, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, c->d_partials, g, 1, g, dst);
@@ -1137,6 +1367,62 @@ extern "C" int hipeig_pair_arnoldi_step(hipeig_ctx* c, int64_t n, int m, const d
   HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dres, sizeof(double) * (2 * m + 2), hipMemcpyDeviceToHost, c->stream));
   HIPEIG_CHECK(hipStreamSynchronize(c->stream));
   memcpy(out, c->h_scalars, sizeof(double) * (2 * m + 2));
+  return 0;
+}
+
+// The same Arnoldi step with `cols_per_pass` columns per pass over w: 1 = the sequential sweep above (scipy's order of
+// rounding, the default everywhere), 4 = the blocked form (same algebra, 2.5 instead of 4 vector streams per column and
+// a launch per four columns; coefficients agree with the sequential sweep to rounding).  One GPU, vectors beyond the
+// one-workgroup size; anything else takes the sequential sweep.
+extern "C" int hipeig_arnoldi_step_p(hipeig_ctx* c, int64_t n, int m, const double* const* V, double* w, double* out, int cols_per_pass) {
+  HIPEIG_REQUIRE(cols_per_pass == 1 || cols_per_pass == 4, "cols_per_pass must be 1 or 4");
+  if (cols_per_pass == 1 || c->collectives || n <= (int64_t)ARN_SMALL_THREADS * ARN_SMALL_E) return hipeig_arnoldi_step(c, n, m, V, w, out);
+  HIPEIG_REQUIRE(m >= 0 && m <= 600 && out, "bad arguments");
+  double* dres = c->d_scalars + 2560;                  // m + 2 doubles (< 640: the total records sit at 3200)
+  if (arnoldi_blocked<false>(c, n, m, V, nullptr, w, nullptr, dres)) return 4;
+  HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dres, sizeof(double) * (m + 2), hipMemcpyDeviceToHost, c->stream));
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  memcpy(out, c->h_scalars, sizeof(double) * (m + 2));
+  return 0;
+}
+
+extern "C" int hipeig_pair_arnoldi_step_p(hipeig_ctx* c, int64_t n, int m, const double* const* Vre, const double* const* Vim,
+                                          double* wre, double* wim, double* out, int cols_per_pass) {
+  HIPEIG_REQUIRE(cols_per_pass == 1 || cols_per_pass == 4, "cols_per_pass must be 1 or 4");
+  if (cols_per_pass == 1 || c->collectives || n <= (int64_t)ARN_SMALL_THREADS * ARN_SMALL_E)
+    return hipeig_pair_arnoldi_step(c, n, m, Vre, Vim, wre, wim, out);
+  HIPEIG_REQUIRE(m >= 0 && m <= 250 && out, "bad arguments");
+  double* dres = c->d_scalars + 2560;                  // 2m + 2 doubles (< 640: the total records sit at 3200)
+  if (arnoldi_blocked<true>(c, n, m, Vre, Vim, wre, wim, dres)) return 4;
+  HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dres, sizeof(double) * (2 * m + 2), hipMemcpyDeviceToHost, c->stream));
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  memcpy(out, c->h_scalars, sizeof(double) * (2 * m + 2));
+  return 0;
+}
+
+// Split form for several independent steps in a row (the right-hand sides of a lock-step block solve each orthogonalise
+// against their OWN basis): `begin` enqueues the step and an asynchronous copy of its scalars into pinned slot `slot`
+// (0..15, up to 126 doubles each), `end` waits for the stream and hands them over - the host work of one right-hand side
+// then overlaps the kernels of the next instead of the GPU idling at every step's round trip.
+#define ARN_SLOT_DOUBLES 128
+extern "C" int hipeig_pair_arnoldi_step_begin(hipeig_ctx* c, int64_t n, int m, const double* const* Vre, const double* const* Vim,
+                                              double* wre, double* wim, int cols_per_pass, int slot) {
+  HIPEIG_REQUIRE(slot >= 0 && slot < 16 && m >= 0 && 2 * m + 2 <= ARN_SLOT_DOUBLES - 2, "bad slot / too many columns for the split form");
+  HIPEIG_REQUIRE(!c->collectives, "the split form is for one GPU");
+  HIPEIG_REQUIRE(cols_per_pass == 1 || cols_per_pass == 4, "cols_per_pass must be 1 or 4");
+  double* dres = c->d_scalars + 2560;
+  const bool blocked = cols_per_pass != 1 && n > (int64_t)ARN_SMALL_THREADS * ARN_SMALL_E;
+  if (blocked ? arnoldi_blocked<true>(c, n, m, Vre, Vim, wre, wim, dres) : arnoldi_fused<true>(c, n, m, Vre, Vim, wre, wim, dres)) return 4;
+  HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars + 2048 + (size_t)slot * ARN_SLOT_DOUBLES, dres, sizeof(double) * (2 * m + 2),
+                              hipMemcpyDeviceToHost, c->stream));
+  HIPEIG_CHECK(hipEventRecord(c->ev_slot[slot], c->stream));
+  return 0;
+}
+
+extern "C" int hipeig_arnoldi_step_end(hipeig_ctx* c, int slot, int count, double* out) {
+  HIPEIG_REQUIRE(slot >= 0 && slot < 16 && count >= 0 && count <= ARN_SLOT_DOUBLES && out, "bad arguments");
+  HIPEIG_CHECK(hipEventSynchronize(c->ev_slot[slot]));        // this step only: the steps enqueued behind it keep running
+  memcpy(out, c->h_scalars + 2048 + (size_t)slot * ARN_SLOT_DOUBLES, sizeof(double) * count);
   return 0;
 }
 

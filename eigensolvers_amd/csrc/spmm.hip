@@ -223,18 +223,36 @@ struct StoreBlockEpilogue {
   __device__ __forceinline__ void elem(int64_t r, int j, double sum, double& acc) const { Y[r * K + j] = sum; }
 };
 
+// Columns (2p, 2p + 1) of the block are the real and imaginary halves of complex operand p; the epilogue applies the
+// complex shift of a contour solve, y_p = sign*(z*x_p - H x_p) (feast.py:83-90 -> numpyVector.py:152-161), with the
+// roundings of PairEpilogue (spmv.hip): the real part of the shift and the operator sum separately, then the zi term.
+// xl: the packed operand block restricted to this operator's rows.
 template <int K>
+struct ShiftPairBlockEpilogue {
+  double ar, ai, as;                                   // sign*zr, sign*zi, -sign
+  const double* __restrict__ xl;
+  double* __restrict__ Y;
+  __device__ __forceinline__ void elem(int64_t r, int j, double sum, double& acc) const {
+    const int64_t base = r * K + (j & ~1);
+    const double vr = xl[base], vi = xl[base + 1];
+    const double own = (j & 1) ? vi : vr;
+    const double t = add_rn(mul_rn(ar, own), mul_rn(as, sum));
+    Y[r * K + j] = (j & 1) ? fma(ai, vr, t) : fma(-ai, vi, t);
+  }
+};
+
+template <int K, class Epi>
 __global__ void __launch_bounds__(BCOO_THREADS)
-spmm_bcoo_kernel(BcooView T, const double* __restrict__ X, StoreBlockEpilogue<K> epi) {
+spmm_bcoo_kernel(BcooView T, const double* __restrict__ X, Epi epi) {
   extern __shared__ double bcoo_lds[];
   double acc = 0.0;
   bcoo_wg_sweep<K>(T, X, epi, acc, bcoo_lds);
 }
 
-template <int K>
+template <int K, class Epi>
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
 spmm_rowowner_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const double* __restrict__ val,
-                     int64_t nrows, const double* __restrict__ X, StoreBlockEpilogue<K> epi) {
+                     int64_t nrows, const double* __restrict__ X, Epi epi) {
   double acc = 0.0;
   csr_rowowner_block_sweep<K>(rowptr, col, val, nrows, X, epi, acc);
 }
@@ -246,29 +264,34 @@ int hipeig_rowowner_grid(const hipeig_ctx* c, const hipeig_csr* A) {
   return g < 1 ? 1 : (int)g;
 }
 
-// Yb = H Xb on interleaved blocks of width K (local rows); Xb is this rank's slice.
-template <int K>
-static int spmm_block_impl(hipeig_ctx* c, hipeig_csr* A, const double* Xb, double* Yb) {
+// Block product on interleaved blocks of width K (local rows) with the epilogue `epi`; Xb is this rank's slice.
+template <int K, class Epi>
+static int spmm_block_run(hipeig_ctx* c, hipeig_csr* A, const double* Xb, const Epi& epi) {
   if (A->nrows == 0) return 0;
   const int bv = hipeig_block_pick_variant(c, A, K);
   if (bv < 0) return 1;
   const double* xg = nullptr;
   if (hipeig_block_allgather(c, A, K, Xb, &xg)) return 4;
-  StoreBlockEpilogue<K> epi{Yb};
   if (bv == 2) {
-    HIPEIG_CHECK(hipFuncSetAttribute((const void*)spmm_bcoo_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIPEIG_BCOO_LDS_MAX));
+    HIPEIG_CHECK(hipFuncSetAttribute((const void*)spmm_bcoo_kernel<K, Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIPEIG_BCOO_LDS_MAX));
     BcooView t = hipeig_bcoo_view(A, K);
     const int g = hipeig_bcoo_grid(A, K);
     for (int ub = 0; ub < t.nunits; ub += g) {                // one launch per sweep of the windows
       t.unit_begin = ub;
-      hipLaunchKernelGGL(spmm_bcoo_kernel<K>, dim3(g), dim3(BCOO_THREADS), hipeig_bcoo_lds_bytes(A, K), c->stream, t, xg, epi);
+      hipLaunchKernelGGL((spmm_bcoo_kernel<K, Epi>), dim3(g), dim3(BCOO_THREADS), hipeig_bcoo_lds_bytes(A, K), c->stream, t, xg, epi);
     }
   } else {
-    hipLaunchKernelGGL(spmm_rowowner_kernel<K>, dim3(hipeig_rowowner_grid(c, A)), dim3(HIPEIG_BLOCK), 0, c->stream,
+    hipLaunchKernelGGL((spmm_rowowner_kernel<K, Epi>), dim3(hipeig_rowowner_grid(c, A)), dim3(HIPEIG_BLOCK), 0, c->stream,
                        A->d_rowptr, A->d_col, A->d_val, A->nrows, xg, epi);
   }
   HIPEIG_CHECK(hipGetLastError());
   return 0;
+}
+
+// Yb = H Xb
+template <int K>
+static int spmm_block_impl(hipeig_ctx* c, hipeig_csr* A, const double* Xb, double* Yb) {
+  return spmm_block_run<K>(c, A, Xb, StoreBlockEpilogue<K>{Yb});
 }
 
 static int ensure_blk_ws(hipeig_ctx* c, size_t doubles) {
@@ -303,6 +326,46 @@ extern "C" int hipeig_spmm(hipeig_ctx* c, hipeig_csr* A, int k, const double* co
     if (K == 4 ? spmm_block_impl<4>(c, A, Xi, Yi) : spmm_block_impl<8>(c, A, Xi, Yi)) return 1;
     if (hipeig_block_unpack(c, K, ny, kk, Yi, Y + j0)) return 1;
     j0 += kk;
+  }
+  return 0;
+}
+
+// The complex matvec of the contour solves for SEVERAL right-hand sides at once (feast.py:198-200: the m0 solves of one
+// contour point share operator and shift): y_p = sign*(z*x_p - H x_p), p < npairs, complex operands as (re, im) buffers.
+// Four complex operands fill an 8-wide block (two a 4-wide one), so the (index, value) stream of the operator is read
+// once per four operands instead of once each; the shift is applied in the block product's epilogue.  A row-partitioned
+// or direct-only context and npairs = 1 take hipeig_spmv_shift_pair per operand.
+extern "C" int hipeig_spmm_shift_pairs(hipeig_ctx* c, hipeig_csr* A, int npairs, double zr, double zi, double sign,
+                                       const double* const* Xre, const double* const* Xim, double* const* Yre, double* const* Yim) {
+  HIPEIG_REQUIRE(npairs >= 1 && Xre && Xim && Yre && Yim, "bad arguments");
+  HIPEIG_REQUIRE(sign == 1.0 || sign == -1.0, "sign must be +1 or -1");
+  if (A->nrows == 0) return 0;
+  if (npairs == 1 || c->collectives) {
+    for (int p = 0; p < npairs; ++p)
+      if (hipeig_spmv_shift_pair(c, A, zr, zi, sign, Xre[p], Xim[p], Yre[p], Yim[p])) return 1;
+    return 0;
+  }
+  const int64_t nx = A->ncols, ny = A->nrows;
+  if (ensure_blk_ws(c, (size_t)(nx + ny) * BCOO_KMAX)) return 1;
+  double* Xi = c->blk_ws;
+  double* Yi = c->blk_ws + (size_t)nx * BCOO_KMAX;
+  const double ar = sign * zr, ai = sign * zi, as = -sign;
+  for (int p0 = 0; p0 < npairs;) {
+    const int np = (npairs - p0 >= 4) ? 4 : ((npairs - p0 > 2) ? npairs - p0 : (npairs - p0));
+    const int K = (np <= 2) ? 4 : 8;
+    const double* cols[BCOO_KMAX];
+    double* outs[BCOO_KMAX];
+    for (int p = 0; p < np; ++p) {
+      cols[2 * p] = Xre[p0 + p]; cols[2 * p + 1] = Xim[p0 + p];
+      outs[2 * p] = Yre[p0 + p]; outs[2 * p + 1] = Yim[p0 + p];
+    }
+    if (hipeig_block_pack(c, K, nx, 2 * np, cols, Xi)) return 1;
+    int rc;
+    if (K == 4) rc = spmm_block_run<4>(c, A, Xi, ShiftPairBlockEpilogue<4>{ar, ai, as, Xi + A->row_offset * 4, Yi});
+    else rc = spmm_block_run<8>(c, A, Xi, ShiftPairBlockEpilogue<8>{ar, ai, as, Xi + A->row_offset * 8, Yi});
+    if (rc) return rc;
+    if (hipeig_block_unpack(c, K, ny, 2 * np, Yi, outs)) return 1;
+    p0 += np;
   }
   return 0;
 }

@@ -99,6 +99,23 @@ def calculateQuadrature(Amat, guess_b, z, radius, angle, weight, contourEllipseF
     return cls.linearCombination([p1, p2], [mult * phase, mult * phase.conjugate()])
 
 
+def _quadrature_terms_block(cls, Amat, guesses, z, radius, angle, weight, contourEllipseFactor):
+    """The quadrature terms of ONE contour point for all guesses through the backend's block solve hook, when it has one
+    (``HipVector.solveBlock``: the solves share operator and shift, feast.py:198-200, so they can advance in lock step on
+    block products).  Same arithmetic per vector as ``calculateQuadrature``; ``None`` = take the one-by-one path."""
+    b0 = guesses[0]
+    if (not hasattr(cls, "solveBlock") or not b0.hasExactAddition or len(guesses) < 2
+            or not getattr(b0, "options", {}).get("blockSolve", True)):
+        return None
+    if abs(z.imag) < 1e-15:
+        opType, z = "her", z.real
+    else:
+        opType = "gen"
+    phase = contourEllipseFactor * math.cos(angle) + math.sin(angle) * 1j
+    sols = cls.solveBlock(Amat, list(guesses), z, opType=opType)
+    return [cls.real((-0.50 * weight * radius * phase) * Qe) for Qe in sols]
+
+
 def updateQ(Q, im0, Qquad_k, k):
     """Accumulate the k-th quadrature term into the im0-th filtered vector (feast.py:105-121)."""
     if k == 0:
@@ -137,8 +154,10 @@ def feastDiagonalization(A, Y, nc, quad, eMin, eMax, eConv, maxit, contourEllips
                 continue
             status["quadrature"] = k
             theta, z = contour_point(eMin, eMax, gk[k], contourEllipseFactor)
+            terms = _quadrature_terms_block(cls, A, Y[:nsub], z, radius, theta, wk[k], contourEllipseFactor)
             for im0 in range(nsub):
-                term = calculateQuadrature(A, Y[im0], z, radius, theta, wk[k], contourEllipseFactor)
+                term = terms[im0] if terms is not None else \
+                    calculateQuadrature(A, Y[im0], z, radius, theta, wk[k], contourEllipseFactor)
                 Q = updateQ(Q, im0, term, 0 if Q[im0] is None else 1)
         if contourComm is not None:
             for im0 in range(nsub):

@@ -26,8 +26,9 @@ from . import _lib
 class _Ops:
     """Thin helpers over the C ABI for raw device buffers of one length."""
 
-    def __init__(self, ctx, n):
+    def __init__(self, ctx, n, cols_per_pass=1):
         self.ctx, self.n, self.h = ctx, n, ctx.handle
+        self.cols_per_pass = int(cols_per_pass)        # Arnoldi sweep: 1 = scipy's order of rounding, 4 = blocked (hipeig.h)
 
     def new(self):
         return self.ctx.alloc(self.n)
@@ -73,8 +74,8 @@ class _Ops:
         m = len(vs)
         out = np.empty(m + 2)
         tab = (C.c_void_p * max(m, 1))(*[v.ptr for v in vs])
-        _lib.call("hipeig_arnoldi_step", self.h, self.n, m, C.cast(tab, C.POINTER(C.c_void_p)), w.ptr,
-                  out.ctypes.data_as(C.POINTER(C.c_double)))
+        _lib.call("hipeig_arnoldi_step_p", self.h, self.n, m, C.cast(tab, C.POINTER(C.c_void_p)), w.ptr,
+                  out.ctypes.data_as(C.POINTER(C.c_double)), self.cols_per_pass)
         return float(np.sqrt(out[0])), out[1:m + 1], float(np.sqrt(out[m + 1]))
 
     def combine(self, coeffs, vecs):
@@ -94,8 +95,9 @@ class _PairOps:
 
     dtype = np.complex128
 
-    def __init__(self, ctx, n):
+    def __init__(self, ctx, n, cols_per_pass=1):
         self.r = _Ops(ctx, n)
+        self.cols_per_pass = int(cols_per_pass)
 
     def new(self):
         return (self.r.new(), self.r.new())
@@ -163,10 +165,27 @@ class _PairOps:
         out = np.empty(2 * m + 2)
         tr = (C.c_void_p * max(m, 1))(*[v[0].ptr for v in vs])
         ti = (C.c_void_p * max(m, 1))(*[v[1].ptr for v in vs])
-        _lib.call("hipeig_pair_arnoldi_step", self.r.h, self.r.n, m, C.cast(tr, C.POINTER(C.c_void_p)),
-                  C.cast(ti, C.POINTER(C.c_void_p)), w[0].ptr, w[1].ptr, out.ctypes.data_as(C.POINTER(C.c_double)))
+        _lib.call("hipeig_pair_arnoldi_step_p", self.r.h, self.r.n, m, C.cast(tr, C.POINTER(C.c_void_p)),
+                  C.cast(ti, C.POINTER(C.c_void_p)), w[0].ptr, w[1].ptr, out.ctypes.data_as(C.POINTER(C.c_double)),
+                  self.cols_per_pass)
         h = out[1:2 * m + 1]
         return float(np.sqrt(out[0])), h[0::2] + 1j * h[1::2], float(np.sqrt(out[2 * m + 1]))
+
+    def arnoldi_begin(self, vs, w, slot):
+        """Enqueue the step without waiting for its scalars (pinned slot ``slot``); ``arnoldi_end`` collects them."""
+        m = len(vs)
+        tr = (C.c_void_p * max(m, 1))(*[v[0].ptr for v in vs])
+        ti = (C.c_void_p * max(m, 1))(*[v[1].ptr for v in vs])
+        _lib.call("hipeig_pair_arnoldi_step_begin", self.r.h, self.r.n, m, C.cast(tr, C.POINTER(C.c_void_p)),
+                  C.cast(ti, C.POINTER(C.c_void_p)), w[0].ptr, w[1].ptr, self.cols_per_pass, int(slot))
+
+    def arnoldi_end(self, m, slot):
+        out = np.empty(2 * m + 2)
+        _lib.call("hipeig_arnoldi_step_end", self.r.h, int(slot), 2 * m + 2, out.ctypes.data_as(C.POINTER(C.c_double)))
+        h = out[1:2 * m + 1]
+        return float(np.sqrt(out[0])), h[0::2] + 1j * h[1::2], float(np.sqrt(out[2 * m + 1]))
+
+    SPLIT_MAX_COLS = 62          # 2m + 2 doubles must fit a pinned slot (hipeig.h)
 
     def combine(self, coeffs, vecs):
         cf = np.asarray(coeffs, dtype=np.complex128)
@@ -176,8 +195,11 @@ class _PairOps:
         return (re, im)
 
 
-def _fgmres(ops, matvec, v0, m, atol, cs):
-    """Inner Arnoldi process: A [v_0..v_j] = C B + V H with H held as Q R.
+def _fgmres(ops, v0, m, atol, cs):
+    """Inner Arnoldi process: A [v_0..v_j] = C B + V H with H held as Q R.  A generator: every operator application is
+    ``w = yield ("mv", v)`` and every orthogonalisation step ``yield ("arn", columns, w)`` - the driver decides whether
+    that is one product / one device call, or a column of a block product and one of a batch of steps enqueued back to
+    back for the right-hand sides of a lock-step solve.
 
     Returns (Q, R, B, vs, y, res); without a preconditioner the z vectors are the v's."""
     dt = getattr(ops, "dtype", np.float64)
@@ -189,11 +211,11 @@ def _fgmres(ops, matvec, v0, m, atol, cs):
     breakdown = False
     j = 0
     for j in range(m):
-        w = matvec(vs[-1])
+        w = yield ("mv", vs[-1])
         # ||w||; (1 - C C^H) A, then modified Gram-Schmidt against V: one sequential sweep over the
         # columns of [C, V], dot and update per column in that order; ||w|| again and w /= ||w|| when
         # that is finite - all in one device call with the scalars copied back once
-        w_norm, coef, h_last = ops.arnoldi_step(list(cs) + vs, w)
+        w_norm, coef, h_last = yield ("arn", list(cs) + vs, w)
         B[:, j] = coef[:len(cs)]
         hcur = np.zeros(j + 2, dtype=dt)
         hcur[:len(vs)] = coef[len(cs):]
@@ -216,18 +238,18 @@ def _fgmres(ops, matvec, v0, m, atol, cs):
     return Q, R, B[:, :j + 1], vs, y, res
 
 
-def gcrotmk_device(ctx, matvec, b, n, rtol=1e-5, atol=0.0, maxiter=1000, m=20, k=None, complex_pairs=False, x0=None):
-    """Solve A x = b; ``matvec(buf) -> new buf`` applies A on the device.
-
-    With ``complex_pairs`` the vectors are (re, im) pairs of device buffers and the arithmetic is
-    complex (SciPy's gcrotmk on a complex LinearOperator).  Returns ``(x, info, stats)`` with
-    SciPy's ``info`` convention."""
-    ops = _PairOps(ctx, n) if complex_pairs else _Ops(ctx, n)
+def _gcrotmk(ops, ctx, b, n, rtol, atol, maxiter, m, k, complex_pairs, x0, stats):
+    """The solver as a generator (``A v = yield v``); returns ``(x, info)`` with SciPy's ``info`` convention."""
     if k is None:
         k = m
+
+    def mv(v):
+        stats["matvecs"] += 1
+        return v
+
     if x0 is not None:                                 # SciPy: x = x0, r = b - A x0
         x = ops.copy(x0)
-        r = matvec(x)
+        r = yield ("mv", x)
         ops.scal(-1.0, r)
         ops.axpy(1.0, b, r)
     else:
@@ -241,13 +263,8 @@ def gcrotmk_device(ctx, matvec, b, n, rtol=1e-5, atol=0.0, maxiter=1000, m=20, k
     if not np.isfinite(b_norm):
         raise ValueError("RHS must contain only finite numbers")
     atol = max(float(atol), float(rtol) * float(b_norm))
-    stats = {"outer": 0, "matvecs": 0}
     if b_norm == 0:
-        return ops.copy(b), 0, stats
-
-    def mv(v):
-        stats["matvecs"] += 1
-        return matvec(v)
+        return ops.copy(b), 0
 
     CU = []
     j_outer = -1
@@ -255,7 +272,7 @@ def gcrotmk_device(ctx, matvec, b, n, rtol=1e-5, atol=0.0, maxiter=1000, m=20, k
         beta = ops.nrm2(r)
         beta_tol = max(atol, rtol * b_norm)
         if beta <= beta_tol and (j_outer > 0 or CU):
-            r = mv(x)                                  # recompute the residual: r = b - A x
+            r = yield ("mv", mv(x))                    # recompute the residual: r = b - A x
             ops.scal(-1.0, r)
             ops.axpy(1.0, b, r)
             beta = ops.nrm2(r)
@@ -265,8 +282,15 @@ def gcrotmk_device(ctx, matvec, b, n, rtol=1e-5, atol=0.0, maxiter=1000, m=20, k
         ml = m + max(k - len(CU), 0)
         cs = [c for c, u in CU]
         try:
-            Q, R, B, vs, y, pres = _fgmres(ops, mv, ops.scaled(1.0 / beta, r), ml,
-                                           atol=max(atol, rtol * b_norm) / beta, cs=cs)
+            inner = _fgmres(ops, ops.scaled(1.0 / beta, r), ml, atol=max(atol, rtol * b_norm) / beta, cs=cs)
+            try:
+                req = next(inner)
+                while True:
+                    if req[0] == "mv":
+                        mv(req[1])
+                    req = inner.send((yield req))
+            except StopIteration as stop:
+                Q, R, B, vs, y, pres = stop.value
             y = y * beta
         except np.linalg.LinAlgError:
             break
@@ -291,4 +315,72 @@ def gcrotmk_device(ctx, matvec, b, n, rtol=1e-5, atol=0.0, maxiter=1000, m=20, k
             del CU[0]
         CU.append((cx, ux))
     stats["outer"] = j_outer + 1
-    return x, j_outer + 1, stats
+    return x, j_outer + 1
+
+
+def gcrotmk_device(ctx, matvec, b, n, rtol=1e-5, atol=0.0, maxiter=1000, m=20, k=None, complex_pairs=False, x0=None,
+                   cols_per_pass=1):
+    """Solve A x = b; ``matvec(buf) -> new buf`` applies A on the device.
+
+    With ``complex_pairs`` the vectors are (re, im) pairs of device buffers and the arithmetic is
+    complex (SciPy's gcrotmk on a complex LinearOperator).  ``cols_per_pass``: the Arnoldi sweep's columns per pass
+    (1 = SciPy's order of rounding, 4 = blocked; hipeig.h).  Returns ``(x, info, stats)`` with SciPy's ``info`` convention."""
+    ops = _PairOps(ctx, n, cols_per_pass) if complex_pairs else _Ops(ctx, n, cols_per_pass)
+    stats = {"outer": 0, "matvecs": 0}
+    gen = _gcrotmk(ops, ctx, b, n, rtol, atol, maxiter, m, k, complex_pairs, x0, stats)
+    try:
+        req = next(gen)
+        while True:
+            req = gen.send(matvec(req[1]) if req[0] == "mv" else ops.arnoldi_step(req[1], req[2]))
+    except StopIteration as stop:
+        x, info = stop.value
+    return x, info, stats
+
+
+def gcrotmk_device_block(ctx, block_matvec, bs, n, rtol=1e-5, atol=0.0, maxiter=1000, m=20, k=None, complex_pairs=False,
+                         cols_per_pass=1):
+    """The solves ``A x_i = b_i`` for several right-hand sides advanced in LOCK STEP: every solve is the solver above,
+    unchanged - its own Krylov spaces, its own recycle pairs, its own stopping - but their operator applications are
+    collected and handed to ``block_matvec([v_0, v_1, ...]) -> [A v_0, A v_1, ...]`` together, so that they run as block
+    products (one pass over the operator for several vectors).  The right-hand sides of one FEAST contour point share
+    operator and shift (feast.py:198-200).  A solve that has finished simply drops out of the block.
+    Returns ``[(x, info, stats), ...]`` in the order of ``bs``."""
+    results = [None] * len(bs)
+    stats = [{"outer": 0, "matvecs": 0} for _ in bs]
+    gens, opss, req = [], [], {}
+
+    def advance(i, value=None, first=False):
+        try:
+            req[i] = next(gens[i]) if first else gens[i].send(value)
+        except StopIteration as stop:
+            results[i] = stop.value + (stats[i],)
+            req.pop(i, None)
+
+    for i, b in enumerate(bs):
+        ops = _PairOps(ctx, n, cols_per_pass) if complex_pairs else _Ops(ctx, n, cols_per_pass)
+        opss.append(ops)
+        gens.append(_gcrotmk(ops, ctx, b, n, rtol, atol, maxiter, m, k, complex_pairs, None, stats[i]))
+        advance(i, first=True)
+    split = complex_pairs                                 # the split (begin / end) form of the step exists for pairs
+    while req:
+        # the orthogonalisation steps of all right-hand sides that wait for one: enqueued back to back, collected
+        # afterwards, so that the host work of one (QR insert, bookkeeping) runs under the kernels of the next
+        arn = sorted(i for i, r in req.items() if r[0] == "arn")
+        while arn:
+            batch = arn[:16]
+            if split and all(len(req[i][1]) <= _PairOps.SPLIT_MAX_COLS for i in batch):
+                for slot, i in enumerate(batch):
+                    opss[i].arnoldi_begin(req[i][1], req[i][2], slot)
+                for slot, i in enumerate(batch):
+                    advance(i, opss[i].arnoldi_end(len(req[i][1]), slot))
+            else:
+                for i in batch:
+                    advance(i, opss[i].arnoldi_step(req[i][1], req[i][2]))
+            arn = sorted(i for i, r in req.items() if r[0] == "arn")
+        idx = sorted(req)                                     # everybody left waits for a product
+        if not idx:
+            break
+        outs = block_matvec([req[i][1] for i in idx])
+        for i, o in zip(idx, outs):
+            advance(i, o)
+    return results

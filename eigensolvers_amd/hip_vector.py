@@ -357,6 +357,20 @@ class HipCsrOperator:
         _lib.call("hipeig_spmv_shift_pair", self.ctx.handle, self.handle, z.real, z.imag,
                   -1.0 if reverse else 1.0, xr.ptr, xi.ptr, yr.ptr, yi.ptr)
 
+    def apply_shifted_pairs(self, z, xs, reverse=False):
+        """[sign*(z*x - H x) for x in xs] for complex operands xs = [(re, im) DeviceBuffers, ...]: four operands share one
+        pass over the operator (``hipeig_spmm_shift_pairs``).  Returns new (re, im) buffer pairs."""
+        z = complex(z)
+        n = self.nrows
+        ys = [(self.ctx.alloc(n), self.ctx.alloc(n)) for _ in xs]
+        t_xr, k1 = _ptr_table([x[0] for x in xs])
+        t_xi, k2 = _ptr_table([x[1] for x in xs])
+        t_yr, k3 = _ptr_table([y[0] for y in ys])
+        t_yi, k4 = _ptr_table([y[1] for y in ys])
+        _lib.call("hipeig_spmm_shift_pairs", self.ctx.handle, self.handle, len(xs), z.real, z.imag, -1.0 if reverse else 1.0,
+                  t_xr, t_xi, t_yr, t_yi)
+        return ys
+
     def apply_pair(self, xr, xi, yr, yi):
         """(yr, yi) = (H xr, H xi): ``applyOp`` on a complex vector, one sweep where the pair kernel applies."""
         _lib.call("hipeig_spmv_shift_pair", self.ctx.handle, self.handle, 0.0, 0.0, 0.0, xr.ptr, xi.ptr, yr.ptr, yi.ptr)
@@ -586,7 +600,8 @@ class HipVector(AbstractVector):
 
             xbuf, conv, gstats = gcrotmk_device(b.ctx, matvec, b._buf, b._buf.n, rtol=float(o["linear_tol"]),
                                                 atol=float(o["linear_atol"]), maxiter=int(o["linearIter"]),
-                                                x0=None if x0 is None else x0._buf)
+                                                x0=None if x0 is None else x0._buf,
+                                                cols_per_pass=int(o.get("arnoldiColumnsPerPass", 1)))
             res = b._new(xbuf)
             res.last_solve_stats = b.last_solve_stats = {"iterations": gstats["matvecs"], "outer": gstats["outer"]}
             if conv != 0:
@@ -630,6 +645,10 @@ class HipVector(AbstractVector):
         complex shifts and fewer than ``BLOCK_SOLVE_MIN`` right-hand sides take the one-by-one calls."""
         bs = list(bs)
         o = bs[0].options["linearSystemArgs"]
+        if (o["linearSolver"] == "gcrotmk" and (isinstance(sigma, complex) or np.iscomplexobj(sigma)) and x0 is None
+                and len(bs) >= 2 and isinstance(H, HipCsrOperator) and not bs[0].ctx.direct_only and bs[0].ctx.nranks == 1
+                and all(isinstance(b, HipVector) for b in bs)):
+            return HipVector._solve_complex_block(H, bs, complex(sigma), o, reverseGF)
         if (o["linearSolver"] != "minres" or isinstance(sigma, complex) or np.iscomplexobj(sigma)
                 or x0 is not None or len(bs) < HipVector.BLOCK_SOLVE_MIN or not isinstance(H, HipCsrOperator)
                 or bs[0].ctx.direct_only):
@@ -728,12 +747,45 @@ class HipVector(AbstractVector):
                 guess = (x0._buf, zero0)
         x, conv, gstats = gcrotmk_device(ctx, matvec, rhs, n, rtol=float(o["linear_tol"]),
                                          atol=float(o["linear_atol"]), maxiter=int(o["linearIter"]),
-                                         complex_pairs=True, x0=guess)
+                                         complex_pairs=True, x0=guess,
+                                         cols_per_pass=int(o.get("arnoldiColumnsPerPass", 1)))
         res = HipComplexVector(b._new(x[0]), b._new(x[1]))
         res.last_solve_stats = b.last_solve_stats = {"iterations": gstats["matvecs"], "outer": gstats["outer"]}
         if conv != 0:
             raise UserWarning("Warning:: Iterative solver is not converged ")
         return res
+
+    @staticmethod
+    def _solve_complex_block(H, bs, z, o, reverseGF):
+        """The contour solves (z*I - H) x_i = b_i of ONE contour point for all right-hand sides in lock step
+        (feast.py:198-200 runs them one after the other on the same operator and shift): each is the complex GCROT of
+        ``_solve_complex``, unchanged, but their operator applications are collected and run as block products, four
+        complex operands per pass over the operator (``gcrotmk_device_block``, ``hipeig_spmm_shift_pairs``).  Results,
+        ``last_solve_stats`` and the exception on non-convergence are those of the one-by-one solves."""
+        from .gcrotmk import gcrotmk_device_block
+        ctx, n = bs[0].ctx, len(bs[0])
+        H.honour_reduction_option(bs[0].options)
+        rhs = []
+        for b in bs:
+            zero = ctx.alloc(n)
+            _lib.call("hipeig_vec_fill", ctx.handle, zero.ptr, n, 0.0)
+            rhs.append((b._buf, zero))
+
+        def block_matvec(vs):
+            return H.apply_shifted_pairs(z, vs, reverse=reverseGF)
+
+        sols = gcrotmk_device_block(ctx, block_matvec, rhs, n, rtol=float(o["linear_tol"]), atol=float(o["linear_atol"]),
+                                    maxiter=int(o["linearIter"]), complex_pairs=True,
+                                    cols_per_pass=int(o.get("arnoldiColumnsPerPass", 1)))
+        out, failed = [], False
+        for b, (x, conv, gstats) in zip(bs, sols):
+            res = HipComplexVector(b._new(x[0]), b._new(x[1]))
+            res.last_solve_stats = b.last_solve_stats = {"iterations": gstats["matvecs"], "outer": gstats["outer"]}
+            failed = failed or conv != 0
+            out.append(res)
+        if failed:
+            raise UserWarning("Warning:: Iterative solver is not converged ")
+        return out
 
     @staticmethod
     def _multi_dot(vectors, x):

@@ -160,6 +160,21 @@ int hipeig_arnoldi_step(hipeig_ctx* ctx, int64_t n, int m, const double* const* 
 int hipeig_pair_arnoldi_step(hipeig_ctx* ctx, int64_t n, int m, const double* const* Vre, const double* const* Vim,
                              double* wre, double* wim, double* out);
 
+/* The same step with `cols_per_pass` columns per pass over w: 1 = the sequential sweep (scipy's order of rounding); 4 = a
+ * pass applies four columns and forms the next four's products with the updated w together with their 4 x 4 Gram block,
+ * from which the sequential coefficients follow exactly (h_k = <V_k,w> - sum_{l<k} h_l <V_k,V_l>): 2.5 instead of 4 vector
+ * streams per column, a launch per four columns, coefficients equal to the sequential ones to rounding.            */
+int hipeig_arnoldi_step_p(hipeig_ctx* ctx, int64_t n, int m, const double* const* V, double* w, double* out, int cols_per_pass);
+int hipeig_pair_arnoldi_step_p(hipeig_ctx* ctx, int64_t n, int m, const double* const* Vre, const double* const* Vim,
+                               double* wre, double* wim, double* out, int cols_per_pass);
+
+/* Split form of the pair step for several independent steps in a row (the right-hand sides of a lock-step block solve):
+ * begin enqueues the step and an asynchronous copy of its 2m + 2 scalars into pinned slot `slot` (0..15, 2m + 2 <= 126),
+ * end waits for the stream and copies `count` of them out.  One GPU only.                                         */
+int hipeig_pair_arnoldi_step_begin(hipeig_ctx* ctx, int64_t n, int m, const double* const* Vre, const double* const* Vim,
+                                   double* wre, double* wim, int cols_per_pass, int slot);
+int hipeig_arnoldi_step_end(hipeig_ctx* ctx, int slot, int count, double* out);
+
 /* ---- sparse operator: replaces the scipy.sparse / ndarray H handed to the loop ----- */
 /* Host CSR -> device.  rowptr has nrows+1 entries (local rows), col holds GLOBAL column
  * indices in [0, ncols).  Rows may be empty or unsorted; duplicates are summed by the
@@ -217,6 +232,11 @@ int hipeig_csr_pair_info(hipeig_csr* A, int64_t out[2]);
  * Y[j] = H X[j], j < k.  Internally the operands are interleaved so that each non-zero costs
  * one index fetch and one contiguous gather for all k (tall-skinny SpMM).                   */
 int hipeig_spmm(hipeig_ctx* ctx, hipeig_csr* A, int k, const double* const* X, double* const* Y);
+/* The complex matvec of the contour solves for SEVERAL right-hand sides (feast.py:198-200: the m0 solves of a contour point
+ * share operator and shift): Y_p = sign*(z*X_p - H X_p), p < npairs, the complex operands as (re, im) buffers.  Four operands
+ * share one pass over the operator (an 8-wide block product whose epilogue applies the shift).                        */
+int hipeig_spmm_shift_pairs(hipeig_ctx* ctx, hipeig_csr* A, int npairs, double zr, double zi, double sign,
+                            const double* const* Xre, const double* const* Xim, double* const* Yre, double* const* Yim);
 /* Kernel choice of the block product / block solve: 0 = automatic, 1 = row-owner CSR (a wavefront per row,
  * 64-byte gathers from wherever the operand block lives), 2 = column-window blocked (operand windows
  * L2-resident, 8 accumulators per row in LDS).  info[0] = variant of the last block launch, [1] = row

@@ -338,3 +338,57 @@ def test_pair_product_at_the_size_of_the_baseline_operator(hip):
     want_i = hip.HipVector.linearCombination([W, U, HW], [z.real, z.imag, -1.0])
     assert hip.HipVector.linearCombination([hip.HipVector(yr), want_r], [1.0, -1.0]).norm() <= 1e-13 * want_r.norm()
     assert hip.HipVector.linearCombination([hip.HipVector(yi), want_i], [1.0, -1.0]).norm() <= 1e-13 * want_i.norm()
+
+
+@pytest.mark.parametrize("N", [4000, 300_000])
+def test_block_complex_shift_product_matches_the_single_products(hip, N):
+    """hipeig_spmm_shift_pairs (the contour solves of one contour point share operator and shift, feast.py:198-200: four
+    complex operands per pass over the operator, the shift in the block product's epilogue) against
+    hipeig_spmv_shift_pair on each operand, 1..6 operands (8-wide blocks, a 4-wide remainder), both signs."""
+    H = hip.HipCsrOperator.generate(N, 32, seed=7)
+    rng = np.random.default_rng(N)
+    ctx = hip.HipContext.default()
+    z = 0.13 + 0.21j
+    for npairs, reverse in ((1, False), (2, True), (3, False), (4, False), (5, True), (6, False)):
+        xs = [(hip.HipVector(rng.standard_normal(N)), hip.HipVector(rng.standard_normal(N))) for _ in range(npairs)]
+        ys = H.apply_shifted_pairs(z, [(a._buf, b._buf) for a, b in xs], reverse=reverse)
+        for (xr, xi), (yr, yi) in zip(xs, ys):
+            rr, ri = ctx.alloc(N), ctx.alloc(N)
+            H.apply_shifted_pair(z, xr._buf, xi._buf, rr, ri, reverse=reverse)
+            ref = hip.HipVector(rr).array + 1j * hip.HipVector(ri).array
+            got = hip.HipVector(yr).array + 1j * hip.HipVector(yi).array
+            assert np.max(np.abs(got - ref)) <= 1e-14 * np.max(np.abs(ref))
+    if N > 100_000:
+        assert H.block_info()["variant"] == "column-window-blocked"
+
+
+@pytest.mark.parametrize("cols", [1, 4])
+def test_contour_solves_in_lock_step_equal_the_single_solves(hip, cols):
+    """HipVector.solveBlock with a complex shift and gcrotmk: the right-hand sides of one contour point advance in lock
+    step (gcrotmk_device_block; their products are block products), each running the unchanged complex GCROT.  Per
+    right-hand side: the solution of the one-by-one solve to the solve tolerance, residual below the tolerance, about the
+    same number of products (the block product rounds differently, so the count may move by a few).  cols = 4: both paths
+    with the blocked Arnoldi sweep (arnoldiColumnsPerPass)."""
+    N, z = 200_000, 0.02 + 0.05j
+    H = hip.HipCsrOperator.generate(N, 32, seed=7)
+    rng = np.random.default_rng(2)
+    o = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 3000, "linear_tol": 1e-8, "linear_atol": 1e-12,
+                              "arnoldiColumnsPerPass": cols}}
+    bs = [hip.HipVector(rng.standard_normal(N), o) for _ in range(6)]
+    for b in bs:
+        b.normalize()
+    one = [hip.HipVector.solve(H, b, z) for b in bs]
+    its_one = [w.last_solve_stats["iterations"] for w in one]
+    blk = hip.HipVector.solveBlock(H, bs, z)
+    ctx = hip.HipContext.default()
+    for b, w1, wb, it1 in zip(bs, one, blk, its_one):
+        assert isinstance(wb, hip.hip_vector.HipComplexVector)
+        a1, ab = w1.array, wb.array
+        assert np.linalg.norm(ab - a1) <= 1e-6 * np.linalg.norm(a1)
+        assert abs(wb.last_solve_stats["iterations"] - it1) <= max(3, it1 // 20)
+        rr, ri = ctx.alloc(N), ctx.alloc(N)                       # true residual of the lock-step solution
+        H.apply_shifted_pair(z, wb.re._buf, wb.im._buf, rr, ri)
+        res = hip.HipVector(rr).array + 1j * hip.HipVector(ri).array - b.array
+        assert np.linalg.norm(res) <= 5e-8
+    # one right-hand side, blockSolve switched off, and a real shift take the one-by-one path
+    assert len(hip.HipVector.solveBlock(H, bs[:1], z)) == 1

@@ -561,17 +561,23 @@ def test_state_following_by_max_overlap_on_device(hip):
 
 
 # ---------------------------------------------------------------- GCROT(m,k) on the device
-@pytest.mark.parametrize("n,m", [(1000, 0), (1000, 1), (100003, 5), (1 << 20, 40), (3_000_001, 7)])
-def test_arnoldi_step_against_numpy(hip, n, m):
+@pytest.mark.parametrize("cols", [1, 4])
+@pytest.mark.parametrize("n,m", [(1000, 0), (1000, 1), (100003, 5), (100002, 0), (100002, 4), (100002, 9), (1 << 20, 40),
+                                 (3_000_001, 7)])
+def test_arnoldi_step_against_numpy(hip, n, m, cols):
     """hipeig_arnoldi_step / hipeig_pair_arnoldi_step (norm, sequential MGS, norm, scaling in one call)
-    against NumPy's evaluation of the same sequence, real and complex-as-pairs."""
+    against NumPy's evaluation of the same sequence, real and complex-as-pairs.  cols = 4: the blocked form
+    (hipeig_arnoldi_step_p: four columns per pass, sequential coefficients recovered through the block's Gram matrix) -
+    the same algebra, so the same expectations; the columns here are NOT orthonormal, the Gram terms matter."""
     from eigensolvers_amd.gcrotmk import _Ops, _PairOps
     rng = np.random.default_rng(n + m)
     Vh = rng.standard_normal((m, n)) / np.sqrt(n)
     Vih = rng.standard_normal((m, n)) / np.sqrt(n)
+    if m >= 2:
+        Vh[1] += 0.3 * Vh[0]                               # a pair of columns far from orthogonal
     wh, wih = rng.standard_normal(n), rng.standard_normal(n)
     ctx = hip.HipContext.default()
-    ops, pops = _Ops(ctx, n), _PairOps(ctx, n)
+    ops, pops = _Ops(ctx, n, cols), _PairOps(ctx, n, cols)
     V = [hip.HipVector(Vh[j].copy())._buf for j in range(m)]
     w = hip.HipVector(wh.copy())
     nb_d, h_d, na_d = ops.arnoldi_step(V, w._buf)

@@ -1,5 +1,5 @@
 """BASELINE config #5 shape run to the reference's stopping rule (or for argv[2] FEAST iterations); JSON summary on stdout.
-python tools/experiments/feast_profile_run.py [N [maxit]]"""
+python tools/experiments/feast_profile_run.py [N [maxit [arnoldi columns per pass: 1 | 4 [lock-step block solves: 1 | 0]]]]"""
 import json, os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.linalg as la
@@ -8,7 +8,10 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 tol, econv, maxit, m0 = 1e-5, 1e-4, (int(sys.argv[2]) if len(sys.argv) > 2 else 12), 16
 H = ea.HipCsrOperator.generate(N, 32 if N <= 2_000_000 else 64, seed=7)
 Q = la.qr(np.random.default_rng(9).standard_normal((N, m0)), mode="economic")[0]
-opt = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 4000, "linear_tol": tol, "linear_atol": tol * 1e-2}}
+cols = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+block = (int(sys.argv[4]) != 0) if len(sys.argv) > 4 else True
+opt = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 4000, "linear_tol": tol, "linear_atol": tol * 1e-2,
+                            "arnoldiColumnsPerPass": cols}, "blockSolve": block}
 import threading
 def _heartbeat(t0=time.time()):                 # a line a minute: a silent long run is taken for a hung one on the GPU box
     while True:
@@ -22,6 +25,6 @@ with warnings.catch_warnings():
 dt = time.time() - t
 res = ea.true_residual_norms(H, ev, Y, len(Y))
 print(json.dumps({"config": "FEAST, window [-0.21, 0.21], nc = 16 (8 half-contour points), m0 = 16, gcrotmk rtol 1e-5, eConv 1e-4",
-                  "N": N, "nnz": int(H.nnz), "outerIter": int(st["outerIter"]), "residual": (None if st["residual"] is None else float(st["residual"])), "converged": bool(st["residual"] is not None and st["residual"] < econv),
+                  "arnoldi_columns_per_pass": cols, "lock_step_block_solves": block, "N": N, "nnz": int(H.nnz), "outerIter": int(st["outerIter"]), "residual": (None if st["residual"] is None else float(st["residual"])), "converged": bool(st["residual"] is not None and st["residual"] < econv),
                   "seconds": round(dt, 1), "seconds_per_feast_iteration": round(dt / (st["outerIter"] + 1), 1),
                   "eigenvalues_in_window": np.sort(ev[(ev > -0.21) & (ev < 0.21)]).tolist(), "true_residual_norms": res.tolist()}, indent=1))
