@@ -221,7 +221,10 @@ def main(result):
             # the kernel or its layout changed since the counters were collected: do not report stale traffic
             traffic_note = f"stale: counters were collected for kernel signature {pmc.get('signature')}, this run is {signature}"
         else:
-            traffic = pmc["kernels"].get(kname, {}).get("hbm_bytes_per_launch")
+            hits = [v for k, v in pmc["kernels"].items() if kname in k and "hbm_bytes_per_launch" in v]      # rocprofv3 names carry "void", template arguments
+            traffic = hits[0]["hbm_bytes_per_launch"] if hits else None
+            if traffic is None:
+                traffic_note = f"the counter pass holds no kernel named like {kname}"
     except Exception as exc:
         traffic, traffic_note = None, f"profiles/pmc_current.json unreadable: {exc}"
     out = {

@@ -88,7 +88,21 @@ def save_checkpoint(saveDir, Y, S, Hm, coeffs, ev, status, sigma=None, L=None, e
     if keep:
         tag = "" if nranks == 1 else f".r{rank}of{nranks}"
         mine = sorted(glob.glob(os.path.join(saveDir, f"krylov_??????{tag}.npz")))
-        for old in mine[:-keep]:
+        if nranks == 1:
+            doomed = mine[:-keep]
+        else:
+            # Ranks write and prune independently.  A rank that pruned by its OWN newest files could delete the last
+            # iteration every rank still has (keep = 1, or a crash between two ranks' writes): the intersection
+            # latest_checkpoint() takes would then be empty although a complete state existed a moment earlier.  So on a
+            # partitioned run only iterations older than the newest COMPLETE one (minus keep - 1) are removed, and at
+            # least two generations are kept.
+            keep = max(int(keep), 2)
+            common = _iterations_of(saveDir, 0, nranks)
+            for r in range(1, nranks):
+                common &= _iterations_of(saveDir, r, nranks)
+            floor = sorted(common)[-keep] if len(common) >= keep else None
+            doomed = [] if floor is None else [f for f in mine if int(os.path.basename(f)[7:13]) < floor]
+        for old in doomed:
             os.remove(old)
     return name
 
@@ -129,7 +143,10 @@ def latest_checkpoint(saveDir, rank=0, nranks=1):
 
 
 def check_meta(meta, sigma, L, eConv, nranks, path="checkpoint"):
-    """Refuse to continue a run whose parameters differ from the ones the checkpoint was written with."""
+    """Refuse to continue a run whose parameters differ from the ones the checkpoint was written with.  Floats are compared
+    exactly (they survive the JSON round trip bit for bit); a key the checkpoint does not carry is not checked.
+    Remaining failure mode of a partitioned resume: ranks whose directories are not the same shared directory see
+    different file sets and may pick different iterations - resume from a directory every rank can read."""
     for key, now in (("sigma", sigma), ("L", L), ("eConv", eConv), ("nranks", nranks)):
         was = meta.get(key)
         if was is not None and now is not None and was != now:

@@ -56,6 +56,20 @@ __device__ __forceinline__ void lds_add_f64_blk(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// operand gather of the block sweep (16 B of an operand row).  BCOO_GATHER_NT (build-time experiment): non-temporal load.
+#ifndef BCOO_GATHER_NT
+#define BCOO_GATHER_NT 0
+#endif
+typedef double bcoo_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 bcoo_gather(const double2* p) {
+#if BCOO_GATHER_NT
+  const bcoo_d2 v = __builtin_nontemporal_load(reinterpret_cast<const bcoo_d2*>(p));
+  return make_double2(v.x, v.y);
+#else
+  return *p;
+#endif
+}
+
 __device__ __forceinline__ uint32_t bperm_u32(int src_lane, uint32_t v) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
 }
@@ -118,7 +132,7 @@ __device__ __forceinline__ void bcoo_wg_sweep(const BcooView& T, const double* _
         const uint32_t col_t = bperm_u32(src, col);                        \
         row_t[ROUNDS * b + t] = bperm_u32(src, row);                       \
         v_t[ROUNDS * b + t] = bperm_f64(src, V[b]);                        \
-        g[ROUNDS * b + t] = X2[(size_t)col_t * (K / 2) + sub];             \
+        g[ROUNDS * b + t] = bcoo_gather(X2 + (size_t)col_t * (K / 2) + sub); \
       }                                                                    \
     }                                                                      \
     _Pragma("unroll") for (int t = 0; t < ROUNDS * NB; ++t) {              \

@@ -272,6 +272,13 @@ class HipCsrOperator:
             raise ValueError(f'options["reduction"] must be "deterministic" or "fast", got {want!r}')
         if want is None or want == getattr(self, "_reduction", None):
             return
+        if getattr(self, "_reduction_pinned", False):
+            return                                   # set_reduction() on the operator wins over per-vector options
+        if getattr(self, "_reduction", None) is not None:
+            # the mode is a property of the OPERATOR (its kernels), shared by every vector that uses it: two vectors asking
+            # for different modes would flip the kernels back and forth under each other
+            raise ValueError(f'this operator already runs with reduction={self._reduction!r} (asked for by another vector); '
+                             f'a vector with reduction={want!r} needs its own operator, or settle it with H.set_reduction()')
         cur = getattr(self, "_variant", 0)
         _lib.call("hipeig_csr_set_reproducible", self.handle, 1 if want == "deterministic" else 0)
         if want == "deterministic" and cur == 4:
@@ -281,6 +288,19 @@ class HipCsrOperator:
             self.set_variant(4)
             self._moved_by_option = False
         self._reduction = want
+
+    def set_reduction(self, mode):
+        """Pin the reduction mode of this operator ("deterministic": bitwise reproducible kernels only; "fast"; None: back to
+        what the vectors' options ask for) whatever ``options["reduction"]`` later vectors carry."""
+        self._reduction_pinned = False
+        previous, self._reduction = getattr(self, "_reduction", None), None
+        if mode is None:
+            if previous == "deterministic":              # back to the unrestricted kernels, then forget
+                self.honour_reduction_option({"reduction": "fast"})
+                self._reduction = None
+            return
+        self.honour_reduction_option({"reduction": mode})
+        self._reduction_pinned = True
 
     def fixed_point_info(self):
         """(max_i sum_j |a_ij|, max |x| of the last variant-5 operand): what bounds variant 5's absolute error."""
@@ -986,8 +1006,9 @@ class HipComplexVector(AbstractVector):
     @staticmethod
     def solve(H, b, sigma, x0=None, opType="her", reverseGF=False):
         """(sigma I - H) x = b for a complex right-hand side.  Real shift with MINRES: the real operator acts on
-        the halves separately, so the two real systems are solved in lock step (``solveBlock``); everything
-        else is complex GCROT on (re, im) pairs, like a complex shift."""
+        the halves separately, so the two real systems go through ``solveBlock`` - which solves TWO right-hand sides one
+        after the other (the lock-step block kernel pays from three on, ``BLOCK_SOLVE_MIN``); everything else is complex
+        GCROT on (re, im) pairs, like a complex shift."""
         if not isinstance(H, HipCsrOperator):
             raise TypeError("HipComplexVector.solve needs a HipCsrOperator (device-resident CSR)")
         o = b.options["linearSystemArgs"]

@@ -90,3 +90,28 @@ def test_three_processes_exchange_by_peer_writes(tmp_path, chunks):
         assert o["werr"] < 1e-8
         assert o["block"] < 1e-14 and o["block_it"] == [o["it"]] * 3
         assert o["allmax"] == float(P - 1) and o["wait_error"] == 0 and o["exchanges"] > 12
+
+
+@pytest.mark.timeout(900)
+def test_bench_started_plainly_with_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` exactly as a driver would start it - no launcher, no environment - with the RCCL-free
+    communicator (RCCL refuses two ranks on one device): the parent spawns the ranks, they exchange by peer writes, and
+    rank 0's ONE JSON line carries what the first real scaling run needs to explain itself: ranks seen through the
+    communicator, the exchange backend, per-phase times, and a Lanczos run that converges to the single-GPU value."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIPEIG_COMM"] = "direct"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--n", "2000000", "--steps", "5",
+                        "--warmup", "2", "--no-cpu"], capture_output=True, text=True, env=env, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["exchange"]["chosen"] == "direct" and out["config"]["rccl_library"] is None
+    ph = out["phases"]
+    assert ph["gather_ms"] > 0 and ph["product_ms"] > 0 and ph["allreduce_ms"] > 0 and ph["exchange_chunks"] >= 1
+    assert ph["local_sweep_ms"] is not None and ph["remote_sweep_ms"] is not None          # the overlap path ran
+    lz = out["lanczos"]
+    assert lz["converged"] and lz["true_residual_norm"] < 1e-6 and abs(lz["ritz_value"] - 0.2 / 15) < 2e-3
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0

@@ -171,7 +171,11 @@ def test_reduction_option_selects_the_reproducible_kernel(hip):
     W2 = [w.array for w in hip.HipVector.solveBlock(H, xs, 0.02)]
     for a, b in zip(W1, W2):
         np.testing.assert_array_equal(a, b)
+    # the mode belongs to the OPERATOR: a vector asking for the other mode does not flip the kernels under the first one
     o = _opts(); o["reduction"] = "fast"
+    with pytest.raises(ValueError, match="already runs with reduction"):
+        hip.HipVector(g.copy(), o).applyOp(H)
+    H.set_reduction(None)                              # released: the next vector's option is honoured again
     hip.HipVector(g.copy(), o).applyOp(H)
     assert H.last_variant() == "column-window-blocked(workgroup)"
     hip.HipVector.solveBlock(H, [hip.HipVector(x.array, o) for x in xs], 0.02)
@@ -181,13 +185,18 @@ def test_reduction_option_selects_the_reproducible_kernel(hip):
     o = _opts(); o["reduction"] = "deterministic"
     hip.HipVector(guess_vector(100_000, 2).copy(), o).applyOp(Hs)
     assert Hs.last_variant() == "csr-stream"
-    # a pinned fast kernel moves to its reproducible twin and back
+    # a pinned fast kernel moves to its reproducible twin and back; set_reduction on the operator wins over vector options
     H.set_variant(4)
-    hip.HipVector(g.copy(), o).applyOp(H)
+    H.set_reduction("deterministic")
+    hip.HipVector(g.copy(), _opts()).applyOp(H)
     assert H.last_variant() == "column-window-blocked(workgroup, fixed-point)"
-    o = _opts(); o["reduction"] = "fast"
-    hip.HipVector(g.copy(), o).applyOp(H)
+    of = _opts(); of["reduction"] = "fast"
+    hip.HipVector(g.copy(), of).applyOp(H)             # ignored: the operator is pinned
+    assert H.last_variant() == "column-window-blocked(workgroup, fixed-point)"
+    H.set_reduction("fast")
+    hip.HipVector(g.copy(), of).applyOp(H)
     assert H.last_variant() == "column-window-blocked(workgroup)"
+    H.set_reduction(None)
     with pytest.raises(ValueError):
         bad = _opts(); bad["reduction"] = "sloppy"
         hip.HipVector(g.copy(), bad).applyOp(H)
