@@ -54,9 +54,11 @@ static int finalize_to_host(hipeig_ctx* c, int nblocks, int ncols, double* host_
 }
 
 // ---- dot / nrm2 ------------------------------------------------------------------------
+// The total is formed by the kernel's last workgroup (common.h) and stored to `out` - on one GPU the pinned, mapped host
+// word, so that a dot product is ONE launch and a stream wait (round 2: two launches).
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
 dot_kernel(int64_t n, const double* __restrict__ x, const double* __restrict__ y,
-           double* __restrict__ partials) {
+           double* __restrict__ partials, unsigned* counters, double* __restrict__ out) {
   __shared__ double lds[4];
   const int64_t n2 = n >> 1;
   const double2* x2 = reinterpret_cast<const double2*>(x);
@@ -77,15 +79,32 @@ dot_kernel(int64_t n, const double* __restrict__ x, const double* __restrict__ y
   double a = a0 + a1;
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) a = fma(x[n - 1], y[n - 1], a);
   a = block_reduce_sum(a, lds);
-  if (threadIdx.x == 0) partials[blockIdx.x] = a;
+  if (threadIdx.x == 0) store_partial(partials + blockIdx.x, a);
+  if (last_block_ticket(counters, gridDim.x, blockIdx.x)) {
+    const double t = sum_partials_agent(partials, gridDim.x, lds);
+    if (threadIdx.x == 0) *out = t;
+    release_ticket_counter(counters);
+  }
 }
 
 extern "C" int hipeig_dot(hipeig_ctx* c, int64_t n, const double* x, const double* y, double* out) {
   HIPEIG_REQUIRE(out != nullptr, "null output");
   const int g = grid_for(n, 8);
-  hipLaunchKernelGGL(dot_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, x, y, c->d_partials);
+  unsigned* cnt = c->d_counters + 3 * HIPEIG_TICKET_WORDS;
+  const bool direct = !c->collectives && c->h_scalars_dev;
+  hipLaunchKernelGGL(dot_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, x, y, c->d_partials, cnt,
+                     direct ? c->h_scalars_dev : c->d_scalars);
   HIPEIG_CHECK(hipGetLastError());
-  return finalize_to_host(c, g, 1, out);
+  if (direct) {
+    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+    *out = c->h_scalars[0];
+    return 0;
+  }
+  if (hipeig_allreduce_sum(c, c->d_scalars, 1)) return 4;
+  HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  *out = c->h_scalars[0];
+  return 0;
 }
 
 extern "C" int hipeig_nrm2(hipeig_ctx* c, int64_t n, const double* x, double* out) {

@@ -117,9 +117,10 @@ int hipeig_direct_destroy(hipeig_ctx* c) {
   return 0;
 }
 
-// Allocate this rank's two gathered buffers (capacity doubles each) and its flags; handles_out receives the two
-// 64-byte hipIpc handles (buffers, flags).  A previous allocation is released first (its peers must re-attach).
-extern "C" int hipeig_direct_alloc(hipeig_ctx* c, int64_t capacity_doubles, void* handles_out /* 128 bytes */) {
+// Allocate this rank's two gathered buffers (capacity doubles each) and its flags; handles_out receives a 192-byte record:
+// the two 64-byte hipIpc handles (buffers, flags) and the PCI bus id of this rank's device (so that a peer can check that
+// it may address this device before it ever stores to it).  A previous allocation is released first.
+extern "C" int hipeig_direct_alloc(hipeig_ctx* c, int64_t capacity_doubles, void* handles_out /* 192 bytes */) {
   HIPEIG_REQUIRE(capacity_doubles > 0 && handles_out, "bad arguments");
   HIPEIG_REQUIRE(c->nranks <= HIPEIG_MAX_RANKS, "too many ranks for the direct exchange");
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is expected to be 64 bytes");
@@ -147,25 +148,59 @@ extern "C" int hipeig_direct_alloc(hipeig_ctx* c, int64_t capacity_doubles, void
   HIPEIG_CHECK(hipIpcGetMemHandle(&hf, d->flags));
   memcpy(handles_out, &hb, 64);
   memcpy((char*)handles_out + 64, &hf, 64);
+  char bus[64];
+  memset(bus, 0, sizeof(bus));
+  HIPEIG_CHECK(hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, c->device));
+  memcpy((char*)handles_out + 128, bus, 64);
   return 0;
 }
 
-// Map every peer's buffers and flags: all_handles holds nranks records of 128 bytes in rank order (this rank's own
-// record is skipped).  Collective in effect: every rank must have allocated before any rank attaches.
+// Map every peer's buffers and flags: all_handles holds nranks records of 192 bytes in rank order (this rank's own
+// record is skipped).  Collective in effect: every rank must have allocated before any rank attaches.  Refuses - before
+// anything is mapped or written - when a peer's device is not visible here or cannot be addressed from this one: a store
+// to an unreachable peer would be a GPU fault, not an error code.
+#define DIRECT_RECORD 192
 extern "C" int hipeig_direct_attach(hipeig_ctx* c, const void* all_handles) {
   DirectComm* d = c->direct;
   HIPEIG_REQUIRE(d != nullptr && all_handles, "hipeig_direct_alloc first");
   HIPEIG_CHECK(hipSetDevice(c->device));
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) == hipSuccess)
-    for (int p = 0; p < ndev; ++p)
-      if (p != c->device) { (void)hipDeviceEnablePeerAccess(p, 0); (void)hipGetLastError(); }     // already enabled / not a peer: fine
+  HIPEIG_CHECK(hipGetDeviceCount(&ndev));
+  char mine[64];
+  memset(mine, 0, sizeof(mine));
+  HIPEIG_CHECK(hipDeviceGetPCIBusId(mine, (int)sizeof(mine) - 1, c->device));
+  for (int r = 0; r < d->nranks; ++r) {
+    if (r == d->rank) continue;
+    char bus[64];
+    memcpy(bus, (const char*)all_handles + (size_t)r * DIRECT_RECORD + 128, 64);
+    bus[63] = 0;
+    if (strcmp(bus, mine) == 0) continue;                // a rank on this very device (several processes on one GPU)
+    int peer = -1;
+    for (int p = 0; p < ndev && peer < 0; ++p) {
+      char pb[64];
+      memset(pb, 0, sizeof(pb));
+      if (hipDeviceGetPCIBusId(pb, (int)sizeof(pb) - 1, p) == hipSuccess && strcmp(pb, bus) == 0) peer = p;
+    }
+    (void)hipGetLastError();
+    if (peer < 0) {
+      hipeig_set_error("direct exchange: the device of rank %d (%s) is not visible in this process", r, bus);
+      return 4;
+    }
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, c->device, peer) != hipSuccess || !can) {
+      (void)hipGetLastError();
+      hipeig_set_error("direct exchange: device %d cannot address the device of rank %d (%s)", c->device, r, bus);
+      return 4;
+    }
+    (void)hipDeviceEnablePeerAccess(peer, 0);              // already enabled: fine
+    (void)hipGetLastError();
+  }
   direct_close_peers(d);
   for (int r = 0; r < d->nranks; ++r) {
     if (r == d->rank) { d->peer_base[r] = d->base; d->peer_flags[r] = d->flags; continue; }
     hipIpcMemHandle_t hb, hf;
-    memcpy(&hb, (const char*)all_handles + (size_t)r * 128, 64);
-    memcpy(&hf, (const char*)all_handles + (size_t)r * 128 + 64, 64);
+    memcpy(&hb, (const char*)all_handles + (size_t)r * DIRECT_RECORD, 64);
+    memcpy(&hf, (const char*)all_handles + (size_t)r * DIRECT_RECORD + 64, 64);
     HIPEIG_CHECK(hipIpcOpenMemHandle((void**)&d->peer_base[r], hb, hipIpcMemLazyEnablePeerAccess));
     HIPEIG_CHECK(hipIpcOpenMemHandle((void**)&d->peer_flags[r], hf, hipIpcMemLazyEnablePeerAccess));
   }

@@ -324,7 +324,7 @@ def enable_direct_gather(ctx, capacity_doubles, rank=None, world=None):
     except Exception as exc:                                    # noqa: BLE001 - reported, every rank falls back together
         err = f"alloc: {exc}"
     recs = grp.allgather(rec)
-    ok = all(len(r) == 128 for r in recs)
+    ok = all(len(r) == 192 for r in recs)
     if ok:
         try:
             ctx.direct_attach(recs)

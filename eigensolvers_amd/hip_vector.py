@@ -81,13 +81,13 @@ class HipContext:
     GATHER_BACKENDS = {0: "rccl", 1: "direct"}
 
     def direct_alloc(self, capacity_doubles):
-        """This rank's buffers for the direct exchange; returns its 128-byte hipIpc record."""
-        buf = C.create_string_buffer(128)
+        """This rank's buffers for the direct exchange; returns its 192-byte record (two hipIpc handles + PCI bus id)."""
+        buf = C.create_string_buffer(192)
         _lib.call("hipeig_direct_alloc", self.handle, int(capacity_doubles), C.cast(buf, C.c_void_p))
         return bytes(buf.raw)
 
     def direct_attach(self, records):
-        """Map the peers' buffers: ``records`` = every rank's 128-byte record in rank order."""
+        """Map the peers' buffers: ``records`` = every rank's 192-byte record in rank order."""
         blob = b"".join(records)
         buf = C.create_string_buffer(blob, len(blob))
         _lib.call("hipeig_direct_attach", self.handle, C.cast(buf, C.c_void_p))

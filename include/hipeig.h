@@ -68,16 +68,17 @@ int hipeig_vec_allreduce(hipeig_ctx* ctx, double* v, int64_t n);
 /* ---- the operand exchange of a row-partitioned product (numpyVector.py:152: one H@x per MINRES iteration) ------------
  * Two backends behind the same calls: 0 = RCCL's ncclAllGather (default), 1 = direct peer writes - every rank stores its
  * slice into the gathered buffers of its peers over all xGMI links at once (csrc/comm_direct.hip).  The direct backend
- * needs the peers' buffers mapped: hipeig_direct_alloc returns this rank's two hipIpc handles (128 bytes: gathered
- * buffers, arrival flags; capacity in doubles per buffer, at least the gathered length of the largest operator), the host
+ * needs the peers' buffers mapped: hipeig_direct_alloc returns this rank's 192-byte record (two hipIpc handles - gathered
+ * buffers, arrival flags - and the PCI bus id of its device; capacity in doubles per buffer, at least the gathered length
+ * of the largest operator; attach refuses when a peer's device is not visible or not addressable from here), the host
  * side all-gathers the records of all ranks in rank order (eigensolvers_amd.distributed) and hands them to
  * hipeig_direct_attach; hipeig_comm_set_gather_backend then switches (every rank at the same point, nothing in flight).
  * hipeig_comm_gather_info: info[0] backend, [1] attached, [2] capacity, [3] exchanges begun, [4] error word of the
  * bounded waits (0 = none), [5] HIPEIG_GATHER_CHUNKS override (0 = automatic).                                        */
 int hipeig_comm_init_direct(hipeig_ctx* ctx, int nranks, int rank);   /* rank / size without RCCL: every exchange direct */
 int hipeig_comm_set_allreduce_backend(hipeig_ctx* ctx, int backend);  /* small all-reduces: 0 RCCL, 1 the peers' mailboxes */
-int hipeig_direct_alloc(hipeig_ctx* ctx, int64_t capacity_doubles, void* handles128_out);
-int hipeig_direct_attach(hipeig_ctx* ctx, const void* all_handles /* nranks x 128 bytes */);
+int hipeig_direct_alloc(hipeig_ctx* ctx, int64_t capacity_doubles, void* record192_out);
+int hipeig_direct_attach(hipeig_ctx* ctx, const void* all_records /* nranks x 192 bytes */);
 int hipeig_comm_set_gather_backend(hipeig_ctx* ctx, int backend);
 int hipeig_comm_gather_info(hipeig_ctx* ctx, int64_t info[8]);
 /* measurement hooks: per-phase event times of the most recent partitioned product (ms; negative = phase absent):
