@@ -147,6 +147,8 @@ struct hipeig_csr {
   uint32_t* w_off;
   int32_t w_nunits, w_nwin, w_wbits, w_rw, w_wgs_per_sweep;
   int32_t w_csplit;          // workgroups sharing one row block (column splits), 1 = none
+  int32_t w_binbits, w_align; // columns per bin (log2) and whether bins are aligned to 64-element instruction groups
+  int64_t w_slots;           // stream length incl. padding slots (== nnz without alignment)
   // copy of the same layout for the pair sweep (two accumulators per row: units of half the rows), built
   // on the first hipeig_spmv_shift_pair of a large operator
   uint32_t* p_idx;

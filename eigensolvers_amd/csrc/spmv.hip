@@ -678,7 +678,7 @@ static int build_tcoow_layout(hipeig_ctx* c, hipeig_csr* A, int pair) {
   while (wbits > 10 && ((int64_t)1 << (wbits - 1)) >= A->gather_len) --wbits;
   const int nwin = (int)((A->gather_len + ((int64_t)1 << wbits) - 1) >> wbits);
   if (nwin > TCOOW_MAX_WIN) return 2;
-  int binbits = 5;                                     // 32 columns = 2 lines of x per bin (measured: 4..6 equal)                                    // 2 Ki columns = 128 lines of x per bin
+  int binbits = 4;                                     // 16 columns = ONE line of x per bin (with aligned bins: 4 / 5 / 6 / 7 -> 1.90 / 1.93 / 1.95 / 2.01 ms per product)
   if (const char* e = getenv(pair ? "HIPEIG_TCOOW_PAIR_BINBITS" : "HIPEIG_TCOOW_BINBITS")) binbits = atoi(e);     // tuning knob
   if (binbits > wbits) binbits = wbits;
   HIPEIG_REQUIRE(binbits >= 3, "HIPEIG_TCOOW_BINBITS out of range");
@@ -727,15 +727,29 @@ static int build_tcoow_layout(hipeig_ctx* c, hipeig_csr* A, int pair) {
   HIPEIG_CHECK(hipStreamSynchronize(c->stream));
   const size_t ntile = (size_t)nunits * nwin;
   std::vector<uint32_t> off(ntile + 1);
-  uint64_t run = 0;
+  // Bins never straddle a 64-element instruction group and tiles start on group boundaries (round 3; the gaps are
+  // padding slots - index 0xFFFFFFFF, value 0 - that the sweep skips; ~2 % of the stream).  A line of x is then fetched
+  // by exactly ONE gather instruction of one wave: L1 -> L2 read requests per launch 1.829e8 -> 1.704e8, i.e. gather fills
+  // per non-zero 0.468 -> 0.431 against the ideal (1 - exp(-k))/k = 0.426, and 2.083 -> 1.90 ms per product at N = 1e7
+  // (profiles/r03_spmv_aligned_bins.txt).  HIPEIG_TCOOW_ALIGN=0 restores the unaligned stream.
+  const char* al_env = getenv(pair ? "HIPEIG_TCOOW_PAIR_ALIGN" : "HIPEIG_TCOOW_ALIGN");
+  const bool align = !(al_env && atoi(al_env) == 0);
+  uint64_t run = 0, counted = 0;
   for (size_t i = 0; i < ncnt; ++i) {
-    if (i % bpw == 0) off[i / bpw] = (uint32_t)run;
+    if (i % bpw == 0) {
+      if (align) run = (run + 63) & ~(uint64_t)63;
+      off[i / bpw] = (uint32_t)run;
+    }
     const uint32_t n = cnt[i];
+    if (align && n > 0 && n <= 64 && (run & 63) + n > 64) run = (run + 63) & ~(uint64_t)63;
     cnt[i] = (uint32_t)run;                            // exclusive scan in place -> scatter cursors
     run += n;
+    counted += n;
   }
   off[ntile] = (uint32_t)run;
-  HIPEIG_REQUIRE(run == (uint64_t)A->nnz, "TCOO-W count pass lost non-zeros");
+  HIPEIG_REQUIRE(counted == (uint64_t)A->nnz, "TCOO-W count pass lost non-zeros");
+  HIPEIG_REQUIRE(run < ((uint64_t)1 << 32), "blocked stream too long for 32-bit offsets");
+  const size_t nslots = (size_t)run;                   // stream length incl. padding (== nnz without alignment)
   HIPEIG_CHECK(hipMemcpyAsync(d_cur, cnt.data(), ncnt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   uint32_t*& l_off = pair ? A->p_off : A->w_off;       // owned by the operator from the allocation on
   uint32_t*& l_idx = pair ? A->p_idx : A->w_idx;
@@ -749,8 +763,12 @@ static int build_tcoow_layout(hipeig_ctx* c, hipeig_csr* A, int pair) {
       HIPEIG_CHECK(hipExtMallocWithFlags((void**)&l_idx, (size_t)A->nnz * sizeof(uint32_t), hipDeviceMallocUncached));
       HIPEIG_CHECK(hipExtMallocWithFlags((void**)&l_val, (size_t)A->nnz * sizeof(double), hipDeviceMallocUncached));
     } else {
-      HIPEIG_CHECK(hipMalloc((void**)&l_idx, (size_t)A->nnz * sizeof(uint32_t)));
-      HIPEIG_CHECK(hipMalloc((void**)&l_val, (size_t)A->nnz * sizeof(double)));
+      HIPEIG_CHECK(hipMalloc((void**)&l_idx, nslots * sizeof(uint32_t)));
+      HIPEIG_CHECK(hipMalloc((void**)&l_val, nslots * sizeof(double)));
+    }
+    if (nslots != (size_t)A->nnz) {                      // padding slots: sentinel index, zero value
+      HIPEIG_CHECK(hipMemsetAsync(l_idx, 0xFF, nslots * sizeof(uint32_t), c->stream));
+      HIPEIG_CHECK(hipMemsetAsync(l_val, 0, nslots * sizeof(double), c->stream));
     }
   }
   HIPEIG_CHECK(hipMemcpyAsync(l_off, off.data(), (ntile + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -774,6 +792,7 @@ static int build_tcoow_layout(hipeig_ctx* c, hipeig_csr* A, int pair) {
   }
   A->w_nunits = (int)nunits; A->w_nwin = nwin; A->w_wbits = wbits; A->w_rw = (int)rw;
   A->w_csplit = csplit;
+  A->w_binbits = binbits; A->w_align = align ? 1 : 0; A->w_slots = (int64_t)nslots;
   A->w_wgs_per_sweep = per_cu * c->num_cu;
   HIPEIG_CHECK(hipFuncSetAttribute((const void*)spmv_tcoow_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)HIPEIG_TCOOW_LDS_MAX));
@@ -791,7 +810,7 @@ static int build_tcoow_layout(hipeig_ctx* c, hipeig_csr* A, int pair) {
     for (double v : part) m = (v > m || v != v) ? v : m;
     A->absrow_max = m;
   }
-  A->bytes += (int64_t)A->nnz * 12 + (int64_t)(ntile + 1) * 4;
+  A->bytes += (int64_t)nslots * 12 + (int64_t)(ntile + 1) * 4;
   return 0;
 }
 
@@ -971,6 +990,7 @@ extern "C" int hipeig_csr_layout_info(hipeig_csr* A, int64_t out[12]) {
   if (A->last_variant == 4 || A->last_variant == 5) {
     out[1] = A->w_rw; out[2] = A->w_wbits; out[3] = A->w_nunits; out[4] = A->w_nwin; out[5] = A->w_csplit;
     out[6] = A->w_wgs_per_sweep; out[7] = TCOOW_THREADS; out[8] = TCOO_UNROLL;
+    out[11] = A->w_binbits + 100 * A->w_align;
   } else if (A->last_variant == 3) {
     out[1] = A->t_rw; out[2] = A->t_wbits; out[3] = A->t_nunits; out[4] = A->t_nwin; out[6] = A->t_wgs_per_sweep;
     out[7] = HIPEIG_BLOCK; out[8] = TCOO_UNROLL;

@@ -331,7 +331,7 @@ class HipCsrOperator:
         out = (C.c_int64 * 12)()
         _lib.call("hipeig_csr_layout_info", self.handle, out)
         keys = ("variant", "rows_per_block", "window_bits", "row_blocks", "windows", "column_splits", "workgroups_per_launch",
-                "threads", "unroll", "exchange_chunks", "rows_per_rank_chunk")
+                "threads", "unroll", "exchange_chunks", "rows_per_rank_chunk", "bins")
         return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def launches_per_apply(self):

@@ -197,7 +197,8 @@ int hipeig_csr_destroy(hipeig_ctx* ctx, hipeig_csr* A);
 int hipeig_csr_info(hipeig_csr* A, int64_t info[8]);
 /* layout constants of the blocked copy the last product ran on: out[0] variant, [1] rows per row block, [2] window bits,
  * [3] row blocks, [4] windows, [5] column splits, [6] workgroups per sweep launch, [7] threads per workgroup, [8] batch
- * unroll, [9] chunks of the operand exchange, [10] rows per (rank, chunk) of the gathered layout (0: not partitioned) */
+ * unroll, [9] chunks of the operand exchange, [10] rows per (rank, chunk) of the gathered layout (0: not partitioned),
+ * [11] log2 of the columns per bin + 100 when bins are aligned to 64-element instruction groups                  */
 int hipeig_csr_layout_info(hipeig_csr* A, int64_t out[12]);
 /* copy the device CSR (local rows) back to the host; pass NULL to skip an array          */
 int hipeig_csr_download(hipeig_ctx* ctx, hipeig_csr* A, int64_t* rowptr, int32_t* col,
