@@ -285,6 +285,9 @@ __device__ __forceinline__ void lds_add_f64_wg(double* p, double v) {
 #ifndef TCOOW_GATHER_MODE
 #define TCOOW_GATHER_MODE 0
 #endif
+#ifndef TCOOW_GIF
+#define TCOOW_GIF 1          // gather instructions of a batch in flight per wave (1: each waited for before the next)
+#endif
 __device__ __forceinline__ double tcoow_gather(const double* p) {
 #if TCOOW_GATHER_MODE == 1
   return __builtin_nontemporal_load(p);
@@ -416,7 +419,16 @@ __device__ __forceinline__ void tcoo_wg_sweep(const TcooView& T, const double* _
       cw[j] = c;                                                                       \
     }                                                                                  \
     double V2[TCOO_UNROLL];                                                            \
-    if (!(TCOO_ABL(T, 1))) {                                                             \
+    if (TCOOW_GIF > 1 && !PAIR) {                                                      \
+      /* build-time experiment: all gathers of the batch issued before the first is waited for (clamped index */ \
+      /* for padding lanes, whose products are never added)                                                  */ \
+      double xg[TCOO_UNROLL];                                                          \
+      _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j) {                        \
+        const size_t gi = (ID[j] != 0xFFFFFFFFu) ? ((size_t)cw[j] << T.wbits) + (ID[j] & cmask) : 0; \
+        xg[j] = tcoow_gather(x + gi);                                                  \
+      }                                                                                \
+      _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j) V[j] *= xg[j];           \
+    } else if (!(TCOO_ABL(T, 1))) {                                                      \
       _Pragma("unroll") for (int j = 0; j < TCOO_UNROLL; ++j)                          \
         if (ID[j] != 0xFFFFFFFFu) {                                                    \
           const size_t gi = ((size_t)((TCOO_ABL(T, 8)) ? 0 : cw[j]) << T.wbits) + (ID[j] & cmask); \
