@@ -353,14 +353,18 @@ def attach_direct(ctx, capacity_doubles, rank=None, world=None):
 
 def choose_gather_backend(ctx, H, group, reps=5):
     """Time ``reps`` products of the partitioned operator ``H`` with each exchange backend, check that they give the same
-    result (to rounding: the blocked sweep adds a row's terms in no fixed order), and switch every rank to the faster one (max over ranks decides, so all ranks agree).  The direct
-    backend must have been attached (``enable_direct_gather``).  Returns a record of what was measured."""
+    results (to rounding: the blocked sweep adds a row's terms in no fixed order), and switch every rank to the faster
+    one (max over ranks decides, so all ranks agree).  The operand CHANGES from product to product (x, 2x, 3x, ...), so a
+    backend that handed the sweep a stale buffer - the previous exchange's data - would be caught, not only one that
+    delivers wrong data outright.  The direct backend must have been attached (``enable_direct_gather``).  Returns a
+    record of what was measured."""
     import numpy as np
+    from . import _lib
     from .hip_vector import HipVector
     n = H.nrows
     x = HipVector(np.random.default_rng(4242 + ctx.rank).standard_normal(n), ctx=ctx)
-    y = {}
-    times = {}
+    xs = ctx.alloc(n)
+    ys, times = {}, {}
     for name in ("rccl", "direct"):
         ctx.set_gather_backend(name)
         out = ctx.alloc(n)
@@ -370,9 +374,16 @@ def choose_gather_backend(ctx, H, group, reps=5):
         for _ in range(reps):
             H.apply_shifted(0.0, x._buf, out)
         times[name] = group.allmax(ctx.timer_stop() / reps)
-        y[name] = HipVector(out).array
-    scale = float(np.max(np.abs(y["rccl"]))) if n else 0.0
-    same = bool(np.all(np.abs(y["rccl"] - y["direct"]) <= 1e-12 * scale)) and ctx.gather_info()["wait_error"] == 0
+        got = []
+        for i in range(2 * reps):                               # both buffers of the double-buffered exchange, several times
+            _lib.call("hipeig_scale", ctx.handle, n, float(i + 1), x._buf.ptr, xs.ptr)
+            H.apply_shifted(0.0, xs, out)
+            got.append(HipVector(out).array / (i + 1))          # every product must equal -H x
+        ys[name] = got
+    scale = float(np.max(np.abs(ys["rccl"][0]))) if n else 0.0
+    same = ctx.gather_info()["wait_error"] == 0
+    for a, b in zip(ys["rccl"], ys["direct"]):
+        same = same and bool(np.all(np.abs(a - b) <= 1e-12 * scale)) and bool(np.all(np.abs(a - ys["rccl"][0]) <= 1e-12 * scale))
     same = group.allmax(0.0 if same else 1.0) == 0.0
     pick = "direct" if (same and times["direct"] < times["rccl"]) else "rccl"
     ctx.set_gather_backend(pick)
@@ -384,7 +395,7 @@ def choose_gather_backend(ctx, H, group, reps=5):
     pick_ar = "direct" if (same and ar["direct"] < ar["rccl"]) else "rccl"
     ctx.set_allreduce_backend(pick_ar)
     return {"rccl_ms": round(times["rccl"], 4), "direct_ms": round(times["direct"], 4), "results_agree": same,
-            "chosen": pick, "reps": reps, "allreduce_rccl_ms": round(ar["rccl"], 4),
+            "products_compared": 2 * reps, "chosen": pick, "reps": reps, "allreduce_rccl_ms": round(ar["rccl"], 4),
             "allreduce_direct_ms": round(ar["direct"], 4), "allreduce_chosen": pick_ar}
 
 

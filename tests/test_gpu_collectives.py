@@ -51,6 +51,14 @@ H2.set_variant(2)
 w2 = ea.HipVector.solve(H2, b2, 0.02); it2 = w2.last_solve_stats["iterations"]
 d = ea.HipVector.linearCombination([w4, w2], [1.0, -1.0])
 out.update(overlap_minres_rel=d.norm() / w2.norm(), it4=it4, it2=it2, coll=w2.last_solve_stats["collectives"])
+# the backend choice bench.py makes per operator on a multi-GPU node (RCCL all-gather vs direct peer writes), here with
+# one rank: both backends run the same changing operands, results compared product by product, the faster one kept
+from eigensolvers_amd import distributed as D
+assert D.enable_direct_gather(ctx, D.gathered_capacity(N2, 1), 0, 1)
+H3 = ea.HipCsrOperator.generate(N2, 32, seed=5, ctx=ctx)          # created with the direct buffers in place
+out["choice"] = D.choose_gather_backend(ctx, H3, D.DeviceGroup(ctx), reps=3)
+out["gather_info"] = ctx.gather_info()
+ctx.set_gather_backend("rccl"); ctx.set_allreduce_backend("rccl")
 import ctypes
 buf = ctypes.create_string_buffer(512)
 ea._lib.call("hipeig_comm_library", buf, 512)
@@ -76,5 +84,9 @@ def test_forced_collectives_single_rank():
     assert r["it4"] == r["it2"] and r["overlap_minres_rel"] < 1e-8
     enq = 16 * -(-(r["it2"] + 1) // 16)                      # the stop of iteration K is seen in KC of iteration K + 1
     assert r["coll"] == 2 * enq                              # one operand exchange (carrying <y,y>) + one all-reduce per iteration
+    ch = r["choice"]
+    assert ch["results_agree"] and ch["products_compared"] == 6 and ch["chosen"] in ("rccl", "direct")
+    assert ch["rccl_ms"] > 0 and ch["direct_ms"] > 0 and ch["allreduce_rccl_ms"] > 0 and ch["allreduce_direct_ms"] > 0
+    assert r["gather_info"]["direct_attached"] and r["gather_info"]["wait_error"] == 0
     # the collectives run on ROCm's own RCCL, whatever else the process has loaded; no torch on the product path
     assert r["rccl"].startswith("/opt/rocm") and not r["torch_loaded"], r["rccl"]
