@@ -1098,6 +1098,9 @@ static int arnoldi_fused(hipeig_ctx* c, int64_t n, int m, const double* const* V
 #ifndef ARN_P
 #define ARN_P 4
 #endif
+#ifndef ARN_BLOCK_THREADS
+#define ARN_BLOCK_THREADS 256          // threads per workgroup of the blocked sweep (build-time knob)
+#endif
 struct ArnBlockCols { const double* re[ARN_P]; const double* im[ARN_P]; };
 template <bool PAIR> struct ArnBlockShape {
   static constexpr int W = PAIR ? 2 : 1;
@@ -1107,7 +1110,7 @@ template <bool PAIR> struct ArnBlockShape {
 };
 
 template <bool PAIR>
-__global__ void __launch_bounds__(HIPEIG_BLOCK)
+__global__ void __launch_bounds__(ARN_BLOCK_THREADS)
 arnoldi_block_kernel(int64_t n, const double* __restrict__ tin, int nb_in, ArnBlockCols cur, int nb_next, ArnBlockCols nxt,
                      int want_ss, double* __restrict__ wre, double* __restrict__ wim, double* __restrict__ coef_out,
                      double* __restrict__ partials, unsigned* counters, double* __restrict__ tout, double* __restrict__ ss_out) {
@@ -1233,7 +1236,7 @@ arnoldi_block_kernel(int64_t n, const double* __restrict__ tin, int nb_in, ArnBl
   }
   // all NV sums of the workgroup through ONE LDS stage (wave shuffles, one barrier, thread v adds the four wave sums)
   const int G = gridDim.x;
-  __shared__ double red[Sh::NV][HIPEIG_BLOCK / 64];
+  __shared__ double red[Sh::NV][ARN_BLOCK_THREADS / 64];
   {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
@@ -1244,7 +1247,7 @@ arnoldi_block_kernel(int64_t n, const double* __restrict__ tin, int nb_in, ArnBl
     __syncthreads();
     if ((int)threadIdx.x < Sh::NV) {
       double t = red[threadIdx.x][0];
-      for (int w = 1; w < HIPEIG_BLOCK / 64; ++w) t += red[threadIdx.x][w];
+      for (int w = 1; w < ARN_BLOCK_THREADS / 64; ++w) t += red[threadIdx.x][w];
       store_partial(partials + (size_t)threadIdx.x * G + blockIdx.x, t);
     }
   }
@@ -1275,7 +1278,8 @@ static int arnoldi_blocked(hipeig_ctx* c, int64_t n, int m, const double* const*
   // each of them as one narrow front.
   int g = c->num_cu;
   if (const char* e = getenv("HIPEIG_ARNOLDI_PER_THREAD")) g = grid_wide(n, atoi(e) > 0 ? atoi(e) : 16);      // tuning knob (elements per thread)
-  if ((int64_t)g * HIPEIG_BLOCK * 2 > n) g = (int)((n / 2 + HIPEIG_BLOCK - 1) / HIPEIG_BLOCK);
+  if (const char* e = getenv("HIPEIG_ARNOLDI_WGS")) g = atoi(e) > 0 ? atoi(e) : g;                              // tuning knob (workgroups)
+  if ((int64_t)g * ARN_BLOCK_THREADS * 2 > n) g = (int)((n / 2 + ARN_BLOCK_THREADS - 1) / ARN_BLOCK_THREADS);
   if (g < 1) g = 1;
   if (g > 8192) g = 8192;                                      // Sh::NV partial areas of g doubles each
   double* P0 = c->d_partials;
@@ -1295,7 +1299,7 @@ static int arnoldi_blocked(hipeig_ctx* c, int64_t n, int m, const double* const*
   cols(m, &none);
   int nb_next = cols(0, &nxt);
   // first pass: ||w||^2 before and everything block 0 needs (no update); with m == 0 it is also ||w||^2 after
-  hipLaunchKernelGGL((arnoldi_block_kernel<PAIR>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, (const double*)nullptr, 0, none,
+  hipLaunchKernelGGL((arnoldi_block_kernel<PAIR>), dim3(g), dim3(ARN_BLOCK_THREADS), 0, c->stream, n, (const double*)nullptr, 0, none,
                      nb_next, nxt, 1, wre, wim, (double*)nullptr, P0, cnt, tot, dres);
   int flip = 0;
   for (int b0 = 0; b0 < m; b0 += ARN_P) {
@@ -1303,7 +1307,7 @@ static int arnoldi_blocked(hipeig_ctx* c, int64_t n, int m, const double* const*
     const int nb_in = nb_next;
     nb_next = cols(b0 + ARN_P, &nxt);
     const int last = (nb_next == 0);
-    hipLaunchKernelGGL((arnoldi_block_kernel<PAIR>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, tot + 32 * flip, nb_in, cur,
+    hipLaunchKernelGGL((arnoldi_block_kernel<PAIR>), dim3(g), dim3(ARN_BLOCK_THREADS), 0, c->stream, n, tot + 32 * flip, nb_in, cur,
                        nb_next, nxt, last, wre, wim, dres + 1 + W * b0, P0, cnt, tot + 32 * (flip ^ 1),
                        last ? dres + 1 + W * m : (double*)nullptr);
     flip ^= 1;

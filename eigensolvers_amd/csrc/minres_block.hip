@@ -297,7 +297,12 @@ static int minres_block_impl(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   const int gA = (bv == 2) ? hipeig_bcoo_grid(A, K) : hipeig_rowowner_grid(c, A);
   const int nsweepA = (bv == 2) ? (tview.nunits + gA - 1) / gA : 1;
   HIPEIG_REQUIRE((int64_t)nsweepA * gA <= HIPEIG_MAX_PARTIALS, "too many sweeps for the partial-sum buffer");
-  const int gE = grid_for(n * (K / 2), 4);
+  // element-wise kernels: every workgroup sums the previous kernel's gE x K partials in its prologue, so FEWER, fatter
+  // workgroups pay twice (less prologue traffic, fewer partials).  Measured (tools/experiments/mrb_grid_sweep.sh, N = 1e6,
+  // K = 8, ms per block iteration): 4 / 8 / 16 / 32 / 64 items per thread -> 0.483 / 0.483 / 0.469 / 0.463 / 0.496.
+  int per_thread = 32;
+  if (const char* e = getenv("HIPEIG_MRB_PER_THREAD")) per_thread = atoi(e) > 0 ? atoi(e) : 32;
+  const int gE = grid_for(n * (K / 2), per_thread);
   double* pA = c->d_partials;
   double* pC = c->d_partials + MRB_PART_STRIDE;
   double* pD = c->d_partials + 2 * MRB_PART_STRIDE;
