@@ -303,9 +303,10 @@ extern "C" int hipeig_lincomb_block(hipeig_ctx* c, int64_t n, int m, int k, cons
     for (int q = 0; q < k; ++q) HIPEIG_REQUIRE(vecs[j] != outs[q], "an output must not alias an input");
   if (n == 0) return 0;
   // Sources of asynchronous copies are the context's PINNED staging buffers (h_ptrs, h_scalars), never
-  // pageable memory that goes out of scope or is refilled while a copy may still be reading it; the
-  // buffers are reused by later calls, so the stream is drained once before they are rewritten.
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  // pageable memory that goes out of scope or is refilled while a copy may still be reading it.  Only this
+  // function and hipeig_comm_setup_rows (which drains the stream) rewrite them from the host, so it is enough
+  // to wait for the event recorded behind the previous call's last copy - not for the whole stream.
+  HIPEIG_CHECK(hipEventSynchronize(c->ev_stage));
   for (int j = 0; j < m; ++j) c->h_ptrs[j] = vecs[j];
   HIPEIG_CHECK(hipMemcpyAsync((void*)c->d_ptrs, c->h_ptrs, sizeof(double*) * m, hipMemcpyHostToDevice, c->stream));
   const int g = grid_for(n, 2);                       // the per-workgroup coefficient prologue wants long-lived workgroups (measured: n/512 workgroups 8 % slower)
@@ -336,7 +337,7 @@ extern "C" int hipeig_lincomb_block(hipeig_ctx* c, int64_t n, int m, int k, cons
     HIPEIG_CHECK(hipGetLastError());
     dcoef += (size_t)m * KB;
   }
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));       // the staging buffers are free for the next call
+  HIPEIG_CHECK(hipEventRecord(c->ev_stage, c->stream));  // behind the last copy out of the staging buffers
   return 0;
 }
 

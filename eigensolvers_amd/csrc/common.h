@@ -122,6 +122,7 @@ struct hipeig_ctx {
   // phase timing of a partitioned product (hipeig_phase_timing): events on both streams
   int phase_timing;
   hipEvent_t ev_ph[8];
+  hipEvent_t ev_stage;       // behind the last asynchronous copy out of the pinned staging buffers (hipeig_lincomb_block)
   hipEvent_t ev_slot[16];    // one per pinned result slot of the split Arnoldi step (hipeig_pair_arnoldi_step_begin)
   // direct all-gather backend (comm_direct.hip): peers' operand buffers and flags mapped through hipIpc
   struct DirectComm* direct;

@@ -34,6 +34,7 @@ extern "C" int hipeig_ctx_create(int device, hipeig_ctx** out) {
   for (int k = 0; k < HIPEIG_GATHER_MAX_CHUNKS; ++k) HIPEIG_CHECK(hipEventCreateWithFlags(&c->ev_chunk[k], hipEventDisableTiming));
   for (int k = 0; k < 8; ++k) HIPEIG_CHECK(hipEventCreate(&c->ev_ph[k]));
   for (int k = 0; k < 16; ++k) HIPEIG_CHECK(hipEventCreateWithFlags(&c->ev_slot[k], hipEventDisableTiming));
+  HIPEIG_CHECK(hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
   HIPEIG_CHECK(hipMalloc((void**)&c->d_counters, 4 * HIPEIG_TICKET_WORDS * sizeof(unsigned)));
   HIPEIG_CHECK(hipMemset(c->d_counters, 0, 4 * HIPEIG_TICKET_WORDS * sizeof(unsigned)));
   c->partials_doubles = (size_t)HIPEIG_MAX_PARTIALS * HIPEIG_MAX_COLS * HIPEIG_MAX_COLS * 2;   // 8 MiB
@@ -96,6 +97,7 @@ extern "C" int hipeig_ctx_destroy(hipeig_ctx* c) {
   for (int k = 0; k < HIPEIG_GATHER_MAX_CHUNKS; ++k) hipEventDestroy(c->ev_chunk[k]);
   for (int k = 0; k < 8; ++k) hipEventDestroy(c->ev_ph[k]);
   for (int k = 0; k < 16; ++k) hipEventDestroy(c->ev_slot[k]);
+  hipEventDestroy(c->ev_stage);
   hipFree(c->d_counters);
   hipStreamDestroy(c->stream);
   hipStreamDestroy(c->comm_stream);

@@ -319,13 +319,14 @@ def _gcrotmk(ops, ctx, b, n, rtol, atol, maxiter, m, k, complex_pairs, x0, stats
 
 
 def gcrotmk_device(ctx, matvec, b, n, rtol=1e-5, atol=0.0, maxiter=1000, m=20, k=None, complex_pairs=False, x0=None,
-                   cols_per_pass=1):
+                   cols_per_pass=1, ops=None):
     """Solve A x = b; ``matvec(buf) -> new buf`` applies A on the device.
 
     With ``complex_pairs`` the vectors are (re, im) pairs of device buffers and the arithmetic is
     complex (SciPy's gcrotmk on a complex LinearOperator).  ``cols_per_pass``: the Arnoldi sweep's columns per pass
     (1 = SciPy's order of rounding, 4 = blocked; hipeig.h).  Returns ``(x, info, stats)`` with SciPy's ``info`` convention."""
-    ops = _PairOps(ctx, n, cols_per_pass) if complex_pairs else _Ops(ctx, n, cols_per_pass)
+    if ops is None:                                       # ``ops``: another vector-operation provider (the CPU tests pass a NumPy one)
+        ops = _PairOps(ctx, n, cols_per_pass) if complex_pairs else _Ops(ctx, n, cols_per_pass)
     stats = {"outer": 0, "matvecs": 0}
     gen = _gcrotmk(ops, ctx, b, n, rtol, atol, maxiter, m, k, complex_pairs, x0, stats)
     try:
@@ -338,7 +339,7 @@ def gcrotmk_device(ctx, matvec, b, n, rtol=1e-5, atol=0.0, maxiter=1000, m=20, k
 
 
 def gcrotmk_device_block(ctx, block_matvec, bs, n, rtol=1e-5, atol=0.0, maxiter=1000, m=20, k=None, complex_pairs=False,
-                         cols_per_pass=1):
+                         cols_per_pass=1, ops_factory=None):
     """The solves ``A x_i = b_i`` for several right-hand sides advanced in LOCK STEP: every solve is the solver above,
     unchanged - its own Krylov spaces, its own recycle pairs, its own stopping - but their operator applications are
     collected and handed to ``block_matvec([v_0, v_1, ...]) -> [A v_0, A v_1, ...]`` together, so that they run as block
@@ -357,11 +358,14 @@ def gcrotmk_device_block(ctx, block_matvec, bs, n, rtol=1e-5, atol=0.0, maxiter=
             req.pop(i, None)
 
     for i, b in enumerate(bs):
-        ops = _PairOps(ctx, n, cols_per_pass) if complex_pairs else _Ops(ctx, n, cols_per_pass)
+        if ops_factory is not None:
+            ops = ops_factory()
+        else:
+            ops = _PairOps(ctx, n, cols_per_pass) if complex_pairs else _Ops(ctx, n, cols_per_pass)
         opss.append(ops)
         gens.append(_gcrotmk(ops, ctx, b, n, rtol, atol, maxiter, m, k, complex_pairs, None, stats[i]))
         advance(i, first=True)
-    split = complex_pairs                                 # the split (begin / end) form of the step exists for pairs
+    split = complex_pairs and all(hasattr(o, "arnoldi_begin") for o in opss)      # the split (begin / end) step exists for device pairs
     while req:
         # the orthogonalisation steps of all right-hand sides that wait for one: enqueued back to back, collected
         # afterwards, so that the host work of one (QR insert, bookkeeping) runs under the kernels of the next
