@@ -59,11 +59,12 @@ def parse():
 
 
 def kernel_signature(layout):
-    """What a counter profile of the sweep is valid for: the sources of the sweep kernels and the layout constants of the
-    operator copy they ran on.  `profiles/pmc_current.json` carries the signature of the run it was collected from."""
+    """What a counter profile of the sweep is valid for: the sources of the sweep kernels (device code and layout builder)
+    and the layout constants of the operator copy they ran on.  `profiles/pmc_current.json` carries the signature of
+    the run it was collected from."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("spmv_device.h", "spmv.hip", "common.h"):
+    for f in ("spmv_device.h", "spmv.hip"):
         h.update(open(os.path.join(REPO, "eigensolvers_amd", "csrc", f), "rb").read())
     h.update(json.dumps(layout, sort_keys=True).encode())
     return h.hexdigest()[:16]
