@@ -246,3 +246,30 @@ def test_config5_feast_converges_at_2e4(hip):
     assert stl["isConverged"]
     k = int(np.argmin(np.abs(ev - evl[0])))
     assert abs(ev[k] - evl[0]) <= max(1e-10 * abs(evl[0]), 2 * res[k] ** 2 / GAP)
+
+
+def test_config5_feast_converges_at_1e6(hip, op1e6, single_1e6):
+    """BASELINE config #5's recipe at N = 1e6 run to the reference's stopping rule (feast.py:226-231): window [-0.21, 0.21],
+    nc = 16 -> 8 half-contour points, m0 = 16, the contour solves of every point in lock step (block complex-shift
+    products, four-column Arnoldi sweep), gcrotmk rtol 1e-3 - which reaches the same eigenvalue-change residual in the
+    same 8 iterations as rtol 1e-5 at a third of the cost (profiles/r03_config5_feast_n1e6*.json).  All 16 window
+    eigenvalues found, each certified by its residual, the one next to sigma equal to the single-vector Lanczos run's
+    (which the real reference's run pins, test_config2) within the Kato-Temple bound."""
+    N, m0 = 1_000_000, 16
+    Q = la.qr(np.random.default_rng(9).standard_normal((N, m0)), mode="economic")[0]
+    o = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 4000, "linear_tol": 1e-3, "linear_atol": 1e-5,
+                              "arnoldiColumnsPerPass": 4}}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ev, Y, st = hip.feastDiagonalization(op1e6, [hip.HipVector(Q[:, i].copy(), o) for i in range(m0)], 16, "legendre",
+                                             -0.21, 0.21, 1e-4, 12, writeOut=False)
+    assert st["residual"] < 1e-4 and len(Y) == m0 and 4 <= st["outerIter"] <= 9
+    inside = np.sort(ev[(ev > -0.21) & (ev < 0.21)])
+    assert len(inside) == 16
+    targets = np.sort(gapped_params(N, 32, 7)["targets"])
+    assert np.all(np.abs(inside - targets) < 2e-3)
+    res = hip.true_residual_norms(op1e6, ev, Y, m0)
+    assert np.all(res < 1e-2), res                       # eigenvalue error <= res^2 / gap
+    ev1 = single_1e6[0]
+    k = int(np.argmin(np.abs(ev - ev1[0])))
+    assert abs(ev[k] - ev1[0]) <= max(1e-10 * abs(ev1[0]), 2 * res[k] ** 2 / GAP)
