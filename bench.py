@@ -134,23 +134,55 @@ def main(result):
 
     N = a.n
     b, e = D.row_range(N, world, rank)
-    t_gen = time.time()
-    H = ea.HipCsrOperator.generate(N, a.nnz_row, seed=a.seed, row_begin=b, row_end=e, ctx=ctx)
-    if a.variant:
-        H.set_variant(a.variant)
-    barrier()
-    t_gen = time.time() - t_gen
-    nnz_total = int(allsum(float(H.nnz)))
     x = ea.HipVector(np.random.default_rng(100 + rank).standard_normal(e - b), ctx=ctx)
     y = ctx.alloc(e - b)
-    exchange = None
-    if world > 1:
+
+    def make_operator():
+        t0 = time.time()
+        Hn = ea.HipCsrOperator.generate(N, a.nnz_row, seed=a.seed, row_begin=b, row_end=e, ctx=ctx)
+        if a.variant:
+            Hn.set_variant(a.variant)
+        barrier()
+        return Hn, time.time() - t0
+
+    def pick_exchange(Hn):
         if direct_ok and comm_mode == "auto":
-            exchange = D.choose_gather_backend(ctx, H, group, reps=5)      # RCCL vs peer writes, by timing 5 products of each
-        else:
-            gi = ctx.gather_info()
-            exchange = {"chosen": gi["backend"], "allreduce_chosen": gi["allreduce_backend"],
-                        "why": "HIPEIG_COMM=" + comm_mode if comm_mode != "auto" else "direct exchange unavailable (see stderr)"}
+            return D.choose_gather_backend(ctx, Hn, group, reps=5)         # RCCL vs peer writes, by timing 5 products of each
+        gi = ctx.gather_info()
+        return {"chosen": gi["backend"], "allreduce_chosen": gi["allreduce_backend"],
+                "why": "HIPEIG_COMM=" + comm_mode if comm_mode != "auto" else "direct exchange unavailable (see stderr)"}
+
+    exchange = None
+    if world > 1 and "HIPEIG_GATHER_CHUNKS" not in os.environ:
+        # How many chunks the operand exchange is cut into is a property of the operator's column layout, so the choice is
+        # made by building the operator both ways (one chunk: two sweep launches; two chunks: the first chunk's windows run
+        # while the second travels), letting each pick its exchange backend, timing 10 products, and keeping the faster.
+        trials = []
+        for nch in (1, 2):
+            ctx.set_gather_chunks(nch)
+            Hn, tg = make_operator()
+            ex = pick_exchange(Hn)
+            for _ in range(3):
+                Hn.apply_shifted(a.sigma, x._buf, y)
+            barrier()
+            ctx.timer_start()
+            for _ in range(10):
+                Hn.apply_shifted(a.sigma, x._buf, y)
+            ms = allmax(ctx.timer_stop() / 10)
+            trials.append((ms, nch, Hn, tg, ex))
+            del Hn
+        trials.sort(key=lambda t: t[0])
+        ms_best, nch_best, H, t_gen, exchange = trials[0]
+        exchange = dict(exchange, chunks_tried={str(t[1]): round(t[0], 4) for t in trials}, chunks_chosen=nch_best)
+        ctx.set_gather_chunks(nch_best)
+        ctx.set_gather_backend(exchange["chosen"])
+        ctx.set_allreduce_backend(exchange["allreduce_chosen"])
+        del trials
+    else:
+        H, t_gen = make_operator()
+        if world > 1:
+            exchange = pick_exchange(H)
+    nnz_total = int(allsum(float(H.nnz)))
 
     for _ in range(a.warmup):
         H.apply_shifted(a.sigma, x._buf, y)

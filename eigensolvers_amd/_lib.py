@@ -44,6 +44,7 @@ SIGNATURES = {
     "hipeig_direct_attach": [_P, _P],
     "hipeig_comm_set_gather_backend": [_P, C.c_int],
     "hipeig_comm_gather_info": [_P, _I64P],
+    "hipeig_comm_set_gather_chunks": [_P, C.c_int],
     "hipeig_phase_timing": [_P, C.c_int],
     "hipeig_phase_get": [_P, _DP],
     "hipeig_comm_bench_allreduce": [_P, C.c_int, C.c_int, _DP],

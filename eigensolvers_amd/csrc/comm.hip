@@ -524,6 +524,14 @@ double* hipeig_gather_block_slot(hipeig_ctx* c, const GatherLayout& gl, int K) {
   return c->xb_full + gl.slot(c->rank) * K;
 }
 
+// Chunks of the operand exchange for operators created FROM NOW ON (0 = automatic, pick_gather_chunks); existing operators
+// keep the layout their columns were remapped to.  Every rank must set the same value.
+extern "C" int hipeig_comm_set_gather_chunks(hipeig_ctx* c, int nchunks) {
+  HIPEIG_REQUIRE(nchunks >= 0 && nchunks <= HIPEIG_GATHER_MAX_CHUNKS, "chunks must be 0 (automatic) .. 4");
+  c->gather_chunks = nchunks;
+  return 0;
+}
+
 // ---- measurement hooks (bench.py) -------------------------------------------------------------------------------
 // Phase timing of row-partitioned products: on != 0 makes every product record events on both streams.
 extern "C" int hipeig_phase_timing(hipeig_ctx* c, int on) {

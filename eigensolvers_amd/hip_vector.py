@@ -107,6 +107,10 @@ class HipContext:
         code = {v: k for k, v in self.GATHER_BACKENDS.items()}[name]
         _lib.call("hipeig_comm_set_allreduce_backend", self.handle, code)
 
+    def set_gather_chunks(self, nchunks):
+        """Chunks of the operand exchange (1-4; 0 = automatic) for operators created from now on (same on every rank)."""
+        _lib.call("hipeig_comm_set_gather_chunks", self.handle, int(nchunks))
+
     def gather_info(self):
         info = (C.c_int64 * 8)()
         _lib.call("hipeig_comm_gather_info", self.handle, info)

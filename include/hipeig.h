@@ -81,6 +81,8 @@ int hipeig_direct_alloc(hipeig_ctx* ctx, int64_t capacity_doubles, void* record1
 int hipeig_direct_attach(hipeig_ctx* ctx, const void* all_records /* nranks x 192 bytes */);
 int hipeig_comm_set_gather_backend(hipeig_ctx* ctx, int backend);
 int hipeig_comm_gather_info(hipeig_ctx* ctx, int64_t info[8]);
+/* chunks of the operand exchange (1-4; 0 = automatic) for operators created from now on; the same on every rank */
+int hipeig_comm_set_gather_chunks(hipeig_ctx* ctx, int nchunks);
 /* measurement hooks: per-phase event times of the most recent partitioned product (ms; negative = phase absent):
  * out[0] operand exchange, [1] sweep of the rank's own column windows (under the exchange), [2] sweep of the other
  * windows incl. waits for later chunks, [3] whole product, [4] compute stream idle before the first chunk arrived;
