@@ -7,6 +7,8 @@
                       the true residual norm of the returned Ritz pair and the reference's wall time.
 * config3_n1e6.json   config #3 - the same operator, block of 8 (the BLOCK8_* parameters of test_gpu_fullsize.py).
 * config4_n<N>.json   a reduced config-#4 instance: 64 nnz/row at the largest N the container's RAM holds.
+* config5_feast_n<N>.json   config #5's FEAST recipe (feast.py:126-244: window [-0.21, 0.21], nc = 16 -> 8 half-contour points,
+                      m0 = 16, gcrotmk rtol 1e-3) at N = 1e5 - what a few hours of CPU allow (`feast:<N>`).
 
 Inputs come from eigensolvers_amd.generators by seed; only a few hundred bytes of outputs are stored.
 Runs only in the build container (needs /root/reference), CPU only:
@@ -91,6 +93,37 @@ def run_block(p, name):
     print(name, np.sort(ev[:k]), out["cumIter"], out["isConverged"], f"{wall:.0f} s", flush=True)
 
 
+FEAST5 = dict(nnz_row=32, seed=7, m0=16, nc=16, eMin=-0.21, eMax=0.21, eConv=1e-4, maxit=12, linear_tol=1e-3, linear_atol=1e-5,
+              linearIter=4000, guess_seed=9)
+
+
+def run_feast(N, name):
+    """Config #5's recipe (window, 8 half-contour points, m0 = 16, gcrotmk) through the reference's feast.py:126-244."""
+    import scipy.linalg as la
+    from make_golden import import_reference
+    from eigensolvers_amd.generators import gapped_csr_host
+    import_reference()
+    import feast as rf
+    from numpyVector import NumpyVector
+    p = dict(FEAST5, N=N)
+    H = gapped_csr_host(N, p["nnz_row"], seed=p["seed"])
+    Q = la.qr(np.random.default_rng(p["guess_seed"]).standard_normal((N, p["m0"])), mode="economic")[0]
+    opt = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": p["linearIter"], "linear_tol": p["linear_tol"],
+                                "linear_atol": p["linear_atol"]}}
+    t0 = time.time()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ev, Y, st = rf.feastDiagonalization(H, [NumpyVector(Q[:, i].copy(), opt) for i in range(p["m0"])], p["nc"], "legendre",
+                                            p["eMin"], p["eMax"], p["eConv"], p["maxit"], writeOut=False)
+    wall = time.time() - t0
+    out = dict(p)
+    out.update(ev=[float(np.real(e)) for e in ev], outerIter=int(st["outerIter"]), residual=float(st["residual"]), nvec=len(Y),
+               true_residual=_true_residuals(H, ev, Y, len(Y)), reference_wall_s=wall, nnz=int(H.nnz), numpy=np.__version__,
+               scipy=__import__("scipy").__version__)
+    json.dump(out, open(os.path.join(HERE, name), "w"), indent=1)
+    print(name, out["outerIter"], out["residual"], f"{wall:.0f} s", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["config2"]
     for w in what:
@@ -98,6 +131,9 @@ if __name__ == "__main__":
             run_single(CONFIG2, "config2_n1e6.json")
         elif w == "config3":
             run_block(CONFIG3, "config3_n1e6.json")
+        elif w.startswith("feast:"):
+            n = int(float(w.split(":")[1]))
+            run_feast(n, f"config5_feast_n{n}.json")
         elif w.startswith("config4:"):
             n = int(float(w.split(":")[1]))
             p = dict(CONFIG2, N=n, nnz_row=64, eConv=1e-10)
