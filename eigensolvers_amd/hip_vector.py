@@ -42,6 +42,7 @@ class HipContext:
         self.device = int(device)
         self.nranks, self.rank = 1, 0
         self.direct_only = False         # a communicator without RCCL (attach_direct_only): no exchange for block operands
+        self.partitioned = True          # False in replica mode (set_partitioned): whole operators / vectors on every rank
         self._pool = {}
         self._finalizer = weakref.finalize(self, HipContext._destroy, h, self._pool)
 
@@ -138,6 +139,7 @@ class HipContext:
         """False: replica mode - whole operators and vectors on every rank, no implicit collectives;
         only ``allreduce_vector`` exchanges data (FEAST contour replicas)."""
         _lib.call("hipeig_comm_set_partitioned", self.handle, 1 if flag else 0)
+        self.partitioned = bool(flag)
 
     def allreduce_vector(self, buf):
         """SUM of a device buffer over the ranks, in place."""
@@ -670,7 +672,8 @@ class HipVector(AbstractVector):
         bs = list(bs)
         o = bs[0].options["linearSystemArgs"]
         if (o["linearSolver"] == "gcrotmk" and (isinstance(sigma, complex) or np.iscomplexobj(sigma)) and x0 is None
-                and len(bs) >= 2 and isinstance(H, HipCsrOperator) and not bs[0].ctx.direct_only and bs[0].ctx.nranks == 1
+                and len(bs) >= 2 and isinstance(H, HipCsrOperator) and not bs[0].ctx.direct_only
+                and (bs[0].ctx.nranks == 1 or not bs[0].ctx.partitioned)       # whole vectors: one GPU, or FEAST's contour replicas
                 and all(isinstance(b, HipVector) for b in bs)):
             return HipVector._solve_complex_block(H, bs, complex(sigma), o, reverseGF)
         if (o["linearSolver"] != "minres" or isinstance(sigma, complex) or np.iscomplexobj(sigma)

@@ -203,9 +203,9 @@ def test_config5_feast_matches_the_reference_run_at_4000(hip, gapped4000):
 
 def test_config5_feast_converges_at_2e4(hip):
     """The same recipe on a larger operator, run until the reference's stopping rule fires (feast.py:226-231,
-    residual < eConv): N = 2e4, gcrotmk rtol 1e-5, eConv 1e-4 - 7 FEAST iterations = ~900 complex GCROT solves,
-    which is what fits the GPU test budget (the solves are launch-bound below N ~ 1e6; the N = 1e6 run of the
-    same recipe is profiles/r02_config5_feast_n1e6.json).  All 16 window eigenvalues found, each a certified
+    residual < eConv) on CONTOUR REPLICAS: N = 2e4, gcrotmk rtol 1e-3 (the inner tolerance the N = 1e6 run below uses: same
+    iterations and residual as 1e-5 at a third of the cost, EXPERIMENTS.md R3-feast), eConv 1e-4, every replica advancing the
+    16 solves of its contour points in lock step.  All 16 window eigenvalues found, each a certified
     eigenpair, the one next to sigma = 0.02 equal to a Lanczos run's on the same operator.  (Convergence is slow
     by construction: with positiveHalf the reference integrates over a quarter circle, util_funcs.py:161-164.)"""
     from eigensolvers_amd.distributed import ContourReplicas, LoopbackGroup
@@ -219,7 +219,7 @@ def test_config5_feast_converges_at_2e4(hip):
         Hr = hip.HipCsrOperator.generate(N, 32, seed=7, ctx=ctx)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            ev, Y, st = hip.feastDiagonalization(Hr, [hip.HipVector(Q[:, i].copy(), _opts("gcrotmk", 4000, 1e-5), ctx=ctx) for i in range(m0)],
+            ev, Y, st = hip.feastDiagonalization(Hr, [hip.HipVector(Q[:, i].copy(), _opts("gcrotmk", 4000, 1e-3), ctx=ctx) for i in range(m0)],
                                                  16, "legendre", -0.21, 0.21, 1e-4, 12, writeOut=False, contourComm=comm)
         return ev, [y.array for y in Y], st
 
