@@ -7,8 +7,9 @@ stop at n = 1200, so at these sizes parity is checked through size-independent p
   #4  N = 1e7, 64 nnz/row: operator properties, generator slab, one converged Lanczos run
       (the 8-rank row partition of the same operator is tests/test_gpu_loopback.py); the reference's run of the same
       operator family at N = 4e6 (config4_n4000000.json), the largest the build container's RAM allows
-  #5  FEAST, window [-0.21, 0.21], 8 half-contour points: the reference's own run at N = 4000 (golden), and
-      the same recipe at N = 2e4 run to status["residual"] < eConv
+  #5  FEAST, window [-0.21, 0.21], 8 half-contour points: the reference's own runs at N = 4000 and at N = 1e5
+      (config5_feast_n100000.json: equal iteration count, residual to 1e-5 relative, eigenvalues to 1e-11), and the same
+      recipe at N = 2e4 (contour replicas) and N = 1e6 run to status["residual"] < eConv
 
 What certifies an eigenpair without an oracle: ||H y - theta y|| = r implies an eigenvalue within r of
 theta, and within r^2 / gap of it once r is below the gap (Kato-Temple; the 16 target levels of the
@@ -199,6 +200,32 @@ def test_config5_feast_matches_the_reference_run_at_4000(hip, gapped4000):
     assert abs(st["residual"] - float(g["residual"])) <= 1e-2 * float(g["residual"])
     np.testing.assert_allclose(np.sort(ev), np.sort(g["ev"]), rtol=1e-10, atol=0)
     np.testing.assert_allclose(np.sort(ev), np.sort(g["exact_inside"]), rtol=1e-7, atol=0)   # and they are the window's eigenvalues
+
+
+def test_config5_feast_matches_the_reference_run_at_1e5(hip):
+    """Config #5's recipe on the REAL reference at the largest N a session's CPU time allows (tests/golden/make_golden_r3.py
+    feast:100000, 4660 s on 4 threads; feast.py:126-244 through numpyVector.py:147-178, scipy gcrotmk rtol 1e-3): the gapped
+    operator at N = 1e5, window [-0.21, 0.21], nc = 16 -> 8 half-contour points, m0 = 16, eConv 1e-4.  Same FEAST iteration
+    count, the same eigenvalue-change residual and the same 16 window eigenvalues: measured 7 = 7 iterations, residual
+    2.443009793e-05 against 2.443009777e-05, eigenvalues within 7e-15 (the Krylov spaces of the contour solves are the
+    same; only rounding differs), in 38 s against the reference's 4660 s."""
+    g = _golden_json("config5_feast_n100000.json")
+    N, m0 = int(g["N"]), int(g["m0"])
+    H = hip.HipCsrOperator.generate(N, int(g["nnz_row"]), seed=int(g["seed"]))
+    Q = la.qr(np.random.default_rng(int(g["guess_seed"])).standard_normal((N, m0)), mode="economic")[0]
+    o = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": int(g["linearIter"]), "linear_tol": float(g["linear_tol"]),
+                              "linear_atol": float(g["linear_atol"])}}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ev, Y, st = hip.feastDiagonalization(H, [hip.HipVector(Q[:, i].copy(), o) for i in range(m0)], int(g["nc"]), "legendre",
+                                             float(g["eMin"]), float(g["eMax"]), float(g["eConv"]), int(g["maxit"]), writeOut=False)
+    assert len(Y) == int(g["nvec"]) and st["residual"] < float(g["eConv"])
+    assert st["outerIter"] == int(g["outerIter"])
+    assert abs(st["residual"] - float(g["residual"])) <= 1e-5 * float(g["residual"])
+    res = hip.true_residual_norms(H, ev, Y, m0)
+    order, gorder = np.argsort(ev), np.argsort(g["ev"])
+    np.testing.assert_allclose(np.asarray(ev)[order], np.asarray(g["ev"])[gorder], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(np.asarray(res)[order], np.asarray(g["true_residual"])[gorder], rtol=1e-4)
 
 
 def test_config5_feast_converges_at_2e4(hip):
