@@ -92,6 +92,57 @@ def test_three_processes_exchange_by_peer_writes(tmp_path, chunks):
         assert o["allmax"] == float(P - 1) and o["wait_error"] == 0 and o["exchanges"] > 12
 
 
+FEAST_CHILD = r'''
+import json, os, sys, warnings
+import numpy as np
+sys.path.insert(0, %(repo)r)
+import eigensolvers_amd as ea
+from eigensolvers_amd import distributed as D
+
+rank, world, _ = D.world_from_env()
+g = np.load(%(golden)r)
+ctx = ea.HipContext(0)
+D.attach_direct(ctx, D.gathered_capacity(g["A"].shape[0], world), rank, world)
+comm = D.ContourReplicas(ctx)                            # replica mode first, then operator and vectors
+opts = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 1000, "linear_tol": 1e-2}}
+A = ea.HipCsrOperator.from_dense(g["A"], ctx=ctx)
+Y = [ea.HipVector(g["guess"][:, i].copy(), dict(opts), ctx=ctx) for i in range(6)]
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    ev, Yf, st = ea.feastDiagonalization(A, Y, 8, "legendre", 160.0, 166.0, 1e-10, 20, writeOut=False, contourComm=comm)
+info = ctx.gather_info()
+with open(os.path.join(%(outdir)r, "rank%%d.json" %% rank), "w") as f:
+    json.dump({"ev": [float(e) for e in ev], "it": int(st["outerIter"]), "n": len(Yf), "y0": Yf[0].array.tolist(),
+               "wait_error": info["wait_error"], "allreduce_backend": info["allreduce_backend"]}, f)
+D.tcp_group().barrier()
+'''
+
+
+@pytest.mark.timeout(900)
+def test_feast_contour_points_on_three_processes(tmp_path):
+    """BASELINE config #5's mapping - contour points dealt to the ranks, whole operator on each, one all-reduce per filtered
+    vector (SURVEY.md 8e) - on three REAL processes joined by the RCCL-free communicator: the reference's own FEAST case
+    (tests/golden/feast_n100.npz, 4 half-contour points -> 2 + 1 + 1), same iteration count and window eigenvalues as the
+    reference's run, identical data on every rank."""
+    from conftest import GOLDEN
+    from eigensolvers_amd.distributed import launch_local
+    P = 3
+    golden = os.path.join(GOLDEN, "feast_n100.npz")
+    prog = tmp_path / "feast_child.py"
+    prog.write_text(FEAST_CHILD % {"repo": REPO, "golden": golden, "outdir": str(tmp_path)})
+    rc, out = launch_local([str(prog)], P, timeout=600, env_extra={"HIPEIG_DIRECT_WAIT_S": "20"})
+    assert rc == 0, out[-2000:]
+    g = np.load(golden)
+    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(P)]
+    inside = (g["ev"] >= 160.0) & (g["ev"] <= 166.0)
+    assert inside.sum() == 3
+    for o in res:
+        assert o["wait_error"] == 0 and o["allreduce_backend"] == "direct"
+        assert o["ev"] == res[0]["ev"] and o["y0"] == res[0]["y0"]                 # every replica ends with the same data
+        assert o["it"] == int(g["outerIter"]) and o["n"] == int(g["nvec"])
+        np.testing.assert_allclose(np.asarray(o["ev"])[inside], g["ev"][inside], rtol=1e-9)
+
+
 @pytest.mark.timeout(900)
 def test_bench_started_plainly_with_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2` exactly as a driver would start it - no launcher, no environment - with the RCCL-free
