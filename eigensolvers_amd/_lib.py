@@ -75,6 +75,7 @@ SIGNATURES = {
     "hipeig_pair_arnoldi_step": [_P, _I64, C.c_int, _PP, _PP, _P, _P, _DP],
     "hipeig_arnoldi_step_p": [_P, _I64, C.c_int, _PP, _P, _DP, C.c_int],
     "hipeig_pair_arnoldi_step_begin": [_P, _I64, C.c_int, _PP, _PP, _P, _P, C.c_int, C.c_int],
+    "hipeig_pair_arnoldi_step_batch_begin": [_P, _I64, C.c_int, _IP, _PP, _PP, _PP, _PP],
     "hipeig_arnoldi_step_end": [_P, C.c_int, C.c_int, _DP],
     "hipeig_pair_arnoldi_step_p": [_P, _I64, C.c_int, _PP, _PP, _P, _P, _DP, C.c_int],
     "hipeig_csr_create": [_P, _I64, _I64, _I64, _I64P, _I32P, _DP, _PP],

@@ -991,10 +991,21 @@ __device__ __forceinline__ void arn_small_reduce2(double& a, double& b, double* 
   for (int w = 1; w < ARN_SMALL_THREADS / 64; ++w) { a += lds[w]; b += lds[16 + w]; }
 }
 
-template <bool PAIR>
-__global__ void __launch_bounds__(ARN_SMALL_THREADS)
-arnoldi_small_kernel(int n, int m, ArnSmallCols V, double* __restrict__ wre, double* __restrict__ wim, double* __restrict__ dres) {
-  __shared__ double lds[32];
+// column tables of the step: in the kernel arguments (one step per launch) or in LDS (one step per WORKGROUP, below)
+struct ArnColsArg {
+  const ArnSmallCols& V;
+  __device__ __forceinline__ const double* re(int j) const { return V.re[j]; }
+  __device__ __forceinline__ const double* im(int j) const { return V.im[j]; }
+};
+struct ArnColsLds {
+  const double* const* tab;                          // [2][ARN_SMALL_MAXCOLS]
+  __device__ __forceinline__ const double* re(int j) const { return tab[j]; }
+  __device__ __forceinline__ const double* im(int j) const { return tab[ARN_SMALL_MAXCOLS + j]; }
+};
+
+template <bool PAIR, class Cols>
+__device__ __forceinline__ void arnoldi_small_body(int n, int m, const Cols& V, double* __restrict__ wre, double* __restrict__ wim,
+                                                   double* __restrict__ dres, double* lds) {
   const int W = PAIR ? 2 : 1;
   double x[ARN_SMALL_E], y[ARN_SMALL_E];
   double ss = 0.0, zero = 0.0;
@@ -1009,8 +1020,8 @@ arnoldi_small_kernel(int n, int m, ArnSmallCols V, double* __restrict__ wre, dou
   arn_small_reduce2(ss, zero, lds);
   if (threadIdx.x == 0) dres[0] = ss;
   for (int j = 0; j < m; ++j) {
-    const double* __restrict__ vr = V.re[j];
-    const double* __restrict__ vi = PAIR ? V.im[j] : nullptr;
+    const double* __restrict__ vr = V.re(j);
+    const double* __restrict__ vi = PAIR ? V.im(j) : nullptr;
     double re = 0.0, im = 0.0;
 #pragma unroll
     for (int e = 0; e < ARN_SMALL_E; ++e) {
@@ -1052,6 +1063,38 @@ arnoldi_small_kernel(int n, int m, ArnSmallCols V, double* __restrict__ wre, dou
       if (PAIR) wim[i] = scale ? y[e] * alpha : y[e];
     }
   }
+}
+
+template <bool PAIR>
+__global__ void __launch_bounds__(ARN_SMALL_THREADS)
+arnoldi_small_kernel(int n, int m, ArnSmallCols V, double* __restrict__ wre, double* __restrict__ wim, double* __restrict__ dres) {
+  __shared__ double lds[32];
+  arnoldi_small_body<PAIR>(n, m, ArnColsArg{V}, wre, wim, dres, lds);
+}
+
+// Several independent steps in ONE launch, a workgroup each (the right-hand sides of a lock-step block solve at lengths
+// where a step is a single workgroup: launched one after the other they would use one CU of 256 in turn).  The items sit
+// in pinned host memory the device reads directly; each workgroup copies its column table to LDS and writes its scalars
+// straight into its pinned result slot - no copy in either direction is enqueued.
+struct ArnBatchItem {
+  int m, pad;
+  double* wre; double* wim;
+  const double* re[ARN_SMALL_MAXCOLS];
+  const double* im[ARN_SMALL_MAXCOLS];
+};
+#define ARN_SLOT_DOUBLES 128
+
+__global__ void __launch_bounds__(ARN_SMALL_THREADS)
+arnoldi_small_batch_kernel(int n, const ArnBatchItem* __restrict__ items, double* __restrict__ slots) {
+  __shared__ double lds[32];
+  __shared__ const double* tab[2 * ARN_SMALL_MAXCOLS];
+  const ArnBatchItem* it = items + blockIdx.x;
+  const int m = it->m;
+  for (int j = threadIdx.x; j < m; j += ARN_SMALL_THREADS) { tab[j] = it->re[j]; tab[ARN_SMALL_MAXCOLS + j] = it->im[j]; }
+  double* wre = it->wre;
+  double* wim = it->wim;
+  __syncthreads();
+  arnoldi_small_body<true>(n, m, ArnColsLds{tab}, wre, wim, slots + (size_t)blockIdx.x * ARN_SLOT_DOUBLES, lds);
 }
 
 template <bool PAIR>
@@ -1428,7 +1471,6 @@ extern "C" int hipeig_pair_arnoldi_step_p(hipeig_ctx* c, int64_t n, int m, const
 // against their OWN basis): `begin` enqueues the step and an asynchronous copy of its scalars into pinned slot `slot`
 // (0..15, up to 126 doubles each), `end` waits for the stream and hands them over - the host work of one right-hand side
 // then overlaps the kernels of the next instead of the GPU idling at every step's round trip.
-#define ARN_SLOT_DOUBLES 128
 extern "C" int hipeig_pair_arnoldi_step_begin(hipeig_ctx* c, int64_t n, int m, const double* const* Vre, const double* const* Vim,
                                               double* wre, double* wim, int cols_per_pass, int slot) {
   HIPEIG_REQUIRE(slot >= 0 && slot < 16 && m >= 0 && 2 * m + 2 <= ARN_SLOT_DOUBLES - 2, "bad slot / too many columns for the split form");
@@ -1440,6 +1482,43 @@ extern "C" int hipeig_pair_arnoldi_step_begin(hipeig_ctx* c, int64_t n, int m, c
   HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars + 2048 + (size_t)slot * ARN_SLOT_DOUBLES, dres, sizeof(double) * (2 * m + 2),
                               hipMemcpyDeviceToHost, c->stream));
   HIPEIG_CHECK(hipEventRecord(c->ev_slot[slot], c->stream));
+  return 0;
+}
+
+// `count` (<= 16) such steps of length n <= 8192 in one launch (arnoldi_small_batch_kernel): step i has m[i] columns
+// Vre[i * 64 + j], Vim[i * 64 + j] (tables of 64 entries per step), works on (wre[i], wim[i]) and reports into pinned
+// slot i; collect with hipeig_arnoldi_step_end(slot i).  Needs the mapped scalar area (returns 5 without it or for longer
+// vectors: the caller then takes the step-by-step form).
+extern "C" int hipeig_pair_arnoldi_step_batch_begin(hipeig_ctx* c, int64_t n, int count, const int* m, const double* const* Vre,
+                                                    const double* const* Vim, double* const* wre, double* const* wim) {
+  HIPEIG_REQUIRE(count >= 1 && count <= 16 && m && Vre && Vim && wre && wim, "bad arguments");
+  HIPEIG_REQUIRE(!c->collectives, "the split form is for one GPU");
+  if (n > (int64_t)ARN_SMALL_THREADS * ARN_SMALL_E || !c->h_scalars_dev) return 5;
+  if (!c->h_arn_items) {
+    HIPEIG_CHECK(hipHostMalloc(&c->h_arn_items, 16 * sizeof(ArnBatchItem), hipHostMallocMapped));
+    if (hipHostGetDevicePointer(&c->d_arn_items, c->h_arn_items, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      hipHostFree(c->h_arn_items);
+      c->h_arn_items = nullptr;
+      return 5;
+    }
+  }
+  // the previous batch has been collected (every `end` waits for the batch's event) before its items are overwritten
+  HIPEIG_CHECK(hipEventSynchronize(c->ev_slot[0]));
+  ArnBatchItem* items = (ArnBatchItem*)c->h_arn_items;
+  for (int i = 0; i < count; ++i) {
+    HIPEIG_REQUIRE(m[i] >= 0 && m[i] <= ARN_SMALL_MAXCOLS && 2 * m[i] + 2 <= ARN_SLOT_DOUBLES - 2, "too many columns for the split form");
+    items[i].m = m[i]; items[i].pad = 0;
+    items[i].wre = wre[i]; items[i].wim = wim[i];
+    for (int j = 0; j < m[i]; ++j) {
+      items[i].re[j] = Vre[(size_t)i * ARN_SMALL_MAXCOLS + j];
+      items[i].im[j] = Vim[(size_t)i * ARN_SMALL_MAXCOLS + j];
+    }
+  }
+  hipLaunchKernelGGL(arnoldi_small_batch_kernel, dim3(count), dim3(ARN_SMALL_THREADS), 0, c->stream, (int)n,
+                     (const ArnBatchItem*)c->d_arn_items, c->h_scalars_dev + 2048);
+  HIPEIG_CHECK(hipGetLastError());
+  for (int i = 0; i < count; ++i) HIPEIG_CHECK(hipEventRecord(c->ev_slot[i], c->stream));
   return 0;
 }
 

@@ -124,6 +124,8 @@ struct hipeig_ctx {
   hipEvent_t ev_ph[8];
   hipEvent_t ev_stage;       // behind the last asynchronous copy out of the pinned staging buffers (hipeig_lincomb_block)
   hipEvent_t ev_slot[16];    // one per pinned result slot of the split Arnoldi step (hipeig_pair_arnoldi_step_begin)
+  void* h_arn_items;         // pinned, mapped: the items of a batched Arnoldi step (hipeig_pair_arnoldi_step_batch_begin)
+  void* d_arn_items;         // the same as the device sees it
   // direct all-gather backend (comm_direct.hip): peers' operand buffers and flags mapped through hipIpc
   struct DirectComm* direct;
   int gather_backend;        // operand exchange: 0 = RCCL (or loopback), 1 = direct peer writes

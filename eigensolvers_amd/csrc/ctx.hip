@@ -75,6 +75,7 @@ extern "C" int hipeig_ctx_destroy(hipeig_ctx* c) {
   hipFree(c->d_partials);
   hipFree(c->d_scalars);
   hipHostFree(c->h_scalars);
+  if (c->h_arn_items) hipHostFree(c->h_arn_items);
   hipFree(c->d_ptrs);
   hipHostFree(c->h_ptrs);
   hipFree(c->d_mr_state);

@@ -186,6 +186,28 @@ class _PairOps:
         return float(np.sqrt(out[0])), h[0::2] + 1j * h[1::2], float(np.sqrt(out[2 * m + 1]))
 
     SPLIT_MAX_COLS = 62          # 2m + 2 doubles must fit a pinned slot (hipeig.h)
+    BATCH_MAX_N = 8192           # lengths at which a step is ONE workgroup: several steps share a launch
+
+    @staticmethod
+    def arnoldi_begin_batch(opss, reqs):
+        """The steps ``reqs = [(columns, w), ...]`` of up to 16 right-hand sides in one launch, a workgroup each (slots
+        0, 1, ...; collect with ``arnoldi_end``).  Returns False, having done nothing, when the library declines (vectors
+        longer than one workgroup handles)."""
+        cnt, r = len(reqs), opss[0].r
+        ms = (C.c_int * cnt)(*[len(vs) for vs, _ in reqs])
+        tr, ti = (C.c_void_p * (64 * cnt))(), (C.c_void_p * (64 * cnt))()
+        for i, (vs, _) in enumerate(reqs):
+            for j, v in enumerate(vs):
+                tr[64 * i + j], ti[64 * i + j] = v[0].ptr, v[1].ptr
+        wr = (C.c_void_p * cnt)(*[w[0].ptr for _, w in reqs])
+        wi = (C.c_void_p * cnt)(*[w[1].ptr for _, w in reqs])
+        PP = C.POINTER(C.c_void_p)
+        rc = getattr(_lib.load(), "hipeig_pair_arnoldi_step_batch_begin")(r.h, r.n, cnt, ms, C.cast(tr, PP), C.cast(ti, PP),
+                                                                          C.cast(wr, PP), C.cast(wi, PP))
+        if rc == 5:
+            return False
+        _lib.check(rc, "hipeig_pair_arnoldi_step_batch_begin")
+        return True
 
     def combine(self, coeffs, vecs):
         cf = np.asarray(coeffs, dtype=np.complex128)
@@ -366,6 +388,7 @@ def gcrotmk_device_block(ctx, block_matvec, bs, n, rtol=1e-5, atol=0.0, maxiter=
         gens.append(_gcrotmk(ops, ctx, b, n, rtol, atol, maxiter, m, k, complex_pairs, None, stats[i]))
         advance(i, first=True)
     split = complex_pairs and all(hasattr(o, "arnoldi_begin") for o in opss)      # the split (begin / end) step exists for device pairs
+    batched = split and ops_factory is None and n <= _PairOps.BATCH_MAX_N and all(o.cols_per_pass in (1, 4) for o in opss)
     while req:
         # the orthogonalisation steps of all right-hand sides that wait for one: enqueued back to back, collected
         # afterwards, so that the host work of one (QR insert, bookkeeping) runs under the kernels of the next
@@ -373,8 +396,10 @@ def gcrotmk_device_block(ctx, block_matvec, bs, n, rtol=1e-5, atol=0.0, maxiter=
         while arn:
             batch = arn[:16]
             if split and all(len(req[i][1]) <= _PairOps.SPLIT_MAX_COLS for i in batch):
-                for slot, i in enumerate(batch):
-                    opss[i].arnoldi_begin(req[i][1], req[i][2], slot)
+                if not (batched and len(batch) > 1 and
+                        _PairOps.arnoldi_begin_batch([opss[i] for i in batch], [(req[i][1], req[i][2]) for i in batch])):
+                    for slot, i in enumerate(batch):
+                        opss[i].arnoldi_begin(req[i][1], req[i][2], slot)
                 for slot, i in enumerate(batch):
                     advance(i, opss[i].arnoldi_end(len(req[i][1]), slot))
             else:

@@ -176,6 +176,11 @@ int hipeig_pair_arnoldi_step_p(hipeig_ctx* ctx, int64_t n, int m, const double* 
  * end waits for the stream and copies `count` of them out.  One GPU only.                                         */
 int hipeig_pair_arnoldi_step_begin(hipeig_ctx* ctx, int64_t n, int m, const double* const* Vre, const double* const* Vim,
                                    double* wre, double* wim, int cols_per_pass, int slot);
+/* `count` (<= 16) such steps in ONE launch, a workgroup per step, for lengths at which a step is a single workgroup
+ * (n <= 8192): step i has m[i] columns Vre[64 i + j], Vim[64 i + j], works on (wre[i], wim[i]) and reports into slot i
+ * (collect with hipeig_arnoldi_step_end).  Returns 5, having done nothing, for longer vectors (take the step-by-step form). */
+int hipeig_pair_arnoldi_step_batch_begin(hipeig_ctx* ctx, int64_t n, int count, const int* m, const double* const* Vre,
+                                         const double* const* Vim, double* const* wre, double* const* wim);
 int hipeig_arnoldi_step_end(hipeig_ctx* ctx, int slot, int count, double* out);
 
 /* ---- sparse operator: replaces the scipy.sparse / ndarray H handed to the loop ----- */

@@ -601,6 +601,42 @@ def test_arnoldi_step_against_numpy(hip, n, m, cols):
     np.testing.assert_allclose(wr.array + 1j * wi.array, z / np.linalg.norm(z), rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("n", [37, 4000, 8192])
+def test_batched_arnoldi_steps_equal_the_single_steps(hip, n):
+    """hipeig_pair_arnoldi_step_batch_begin: the orthogonalisation steps of several right-hand sides (each against its OWN
+    columns, different counts, one with none) in one launch, a workgroup per step - the same device code as the single
+    step at these lengths, so coefficients, norms and the normalised vectors are bit-identical; a longer vector is
+    declined (the caller then enqueues the steps one by one)."""
+    from eigensolvers_amd.gcrotmk import _PairOps
+    ctx = hip.HipContext.default()
+    rng = np.random.default_rng(n)
+    counts = [0, 1, 7, 40, 62, 3]
+
+    def make():
+        r = np.random.default_rng(n + 1)
+        reqs = []
+        for m in counts:
+            vs = [(hip.HipVector(r.standard_normal(n) / np.sqrt(n))._buf, hip.HipVector(r.standard_normal(n) / np.sqrt(n))._buf)
+                  for _ in range(m)]
+            reqs.append((vs, (hip.HipVector(r.standard_normal(n))._buf, hip.HipVector(r.standard_normal(n))._buf)))
+        return reqs
+
+    opss = [_PairOps(ctx, n) for _ in counts]
+    single = make()
+    ref = [opss[i].arnoldi_step(vs, w) for i, (vs, w) in enumerate(single)]
+    batch = make()
+    assert _PairOps.arnoldi_begin_batch(opss, batch)
+    for slot, (vs, w) in enumerate(batch):
+        nb, h, na = opss[slot].arnoldi_end(len(vs), slot)
+        assert nb == ref[slot][0] and na == ref[slot][2]
+        np.testing.assert_array_equal(h, ref[slot][1])
+        for part, part_ref in zip(w, single[slot][1]):
+            np.testing.assert_array_equal(hip.HipVector(part).array, hip.HipVector(part_ref).array)
+    big = _PairOps(ctx, 8193)
+    wbig = (hip.HipVector(rng.standard_normal(8193))._buf, hip.HipVector(rng.standard_normal(8193))._buf)
+    assert _PairOps.arnoldi_begin_batch([big, big], [([], wbig), ([], wbig)]) is False
+
+
 def test_gcrotmk_tracks_scipy(hip, gapped4000):
     """linearSolver="gcrotmk" (numpyVector.py:161): device GCROT(20,20) against the SciPy routine
     the reference calls, on the shifted gapped operator and on the reference's dense test matrix."""
