@@ -261,8 +261,14 @@ __device__ __forceinline__ double block_sum_partials(const double* __restrict__ 
 // Usage inside a kernel (after every thread that holds a partial has stored it with store_partial):
 //   if (last_block_ticket(counters, tickets, my_slot)) { t = sum_partials_agent(p, count, lds); if (threadIdx.x == 0) *total = t; ...;
 //                                             release_ticket_counter(counter); }
+__device__ __forceinline__ void wait_for_my_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// The storing thread itself waits until the store has been performed (vmcnt counts stores on gfx9): a workgroup-scope
+// release fence emits NO wait on gfx950 (checked in the ISA: store, s_waitcnt lgkmcnt(0), s_barrier, atomic), so without
+// this nothing would order the partial before the ticket that announces it.
 __device__ __forceinline__ void store_partial(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  wait_for_my_stores();
 }
 
 // True, uniformly over the workgroup, in the workgroup that takes the last of `tickets` tickets (my_slot: this workgroup's
@@ -274,9 +280,10 @@ __device__ __forceinline__ void store_partial(double* p, double v) {
 //
 // The partials were stored with agent-scope atomic stores (written through to the point where all XCDs agree) and are
 // read back with agent-scope atomic loads, so what has to be ordered is only "my store has been performed before my
-// ticket is counted": a wait for the outstanding stores (the workgroup-scope release), not an agent-scope release,
-// which on this chip writes back and invalidates the XCD's whole L2 at the end of every workgroup (measured: +15 us per
-// kernel at N = 1e6).
+// ticket is counted": an explicit `s_waitcnt vmcnt(0)` in every storing thread (store_partial) in front of the barrier
+// below, and once more in thread 0 in front of the ticket - NOT an agent-scope release, which on this chip writes back
+// and invalidates the XCD's whole L2 at the end of every workgroup (measured: +15 us per kernel at N = 1e6), and not a
+// workgroup-scope release either, which compiles to no wait at all.
 #define HIPEIG_TICKET_GROUP 64
 #define HIPEIG_TICKET_WORDS (1 + HIPEIG_WIDE_PARTIALS / HIPEIG_TICKET_GROUP + 7)
 __device__ __forceinline__ bool last_block_ticket(unsigned* counters, unsigned tickets, unsigned my_slot) {
@@ -287,6 +294,7 @@ __device__ __forceinline__ bool last_block_ticket(unsigned* counters, unsigned t
     const unsigned g = my_slot / HIPEIG_TICKET_GROUP;
     const unsigned gsize = (g == ng - 1) ? tickets - g * HIPEIG_TICKET_GROUP : HIPEIG_TICKET_GROUP;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    wait_for_my_stores();
     int last = 0;
     if (__hip_atomic_fetch_add(counters + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
       __hip_atomic_store(counters + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -348,7 +348,13 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
   const int nsweepA = split ? 1 : (variant == 4) ? (A->w_nunits + gA - 1) / gA
                     : (variant == 3) ? (A->t_nunits + gA * 4 - 1) / (gA * 4) : 1;
   HIPEIG_REQUIRE(nsweepA * gA <= HIPEIG_WIDE_PARTIALS, "too many sweeps for the partial-sum buffer");
-  const int nPA = split ? gE : gA * nsweepA;                 // partial <v,y> sums one iteration leaves in pA
+  // combine launch of a column-split sweep (slab of a many-GPU run): rows per thread.  It carries the whole KA epilogue with
+  // the riding KD (10 streams + the slabs), not a 2-stream update: 24 / 12 / 8 / 4 / 2 rows per thread -> 0.177 / 0.160 /
+  // 0.156 / 0.160 / 0.166 ms per iteration (N = 1e6, 5 splits forced; profiles/r04_minres_combine_grid.txt)
+  int ct = 8;
+  if (const char* e = getenv("HIPEIG_MR_COMBINE_PER_THREAD")) ct = atoi(e) > 0 ? atoi(e) : 8;   // tuning knob
+  const int gC = grid_wide(n, ct);
+  const int nPA = split ? gC : gA * nsweepA;                 // partial <v,y> sums one iteration leaves in pA
   a.pA = tot + 0; a.nA = 1;
   a.pD = tot + 1; a.nD = 1;
   a.pC = tot + 2; a.nC = 1; a.sC = 0;
@@ -376,8 +382,8 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
 #define KA_LAUNCH(VAR, FIX, GRID, THREADS, LDS, TV, OFF)                                                            \
     do {                                                                                                            \
       MinresKdArgs kl = kd;                                                                                         \
-      kl.red = MinresRed{pD + (OFF), pD, nPA, (unsigned)(split ? gE : nPA), cntD, tot + 1, nullptr};              \
-      const MinresRed ra{pA + (OFF), pA, nPA, (unsigned)(split ? gE : nPA), cntA, tot + 0, nullptr};              \
+      kl.red = MinresRed{pD + (OFF), pD, nPA, (unsigned)nPA, cntD, tot + 1, nullptr};              \
+      const MinresRed ra{pA + (OFF), pA, nPA, (unsigned)nPA, cntA, tot + 0, nullptr};              \
       hipLaunchKernelGGL((minres_ka_kernel<VAR, FIX>), dim3(GRID), dim3(THREADS), LDS, c->stream, view, TV, xg, al, Sin, V + 1, r2, r1, yb, ra, kl, zero_xx); \
     } while (0)
     if (variant == 4) {
@@ -396,7 +402,7 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
         TcooView tc = tv;
         tc.raw_out = c->ytmp;
         tc.part_base = ncombine;                                  // number of slabs to add
-        KA_LAUNCH(5, 0, gE, HIPEIG_BLOCK, 0, tc, 0);
+        KA_LAUNCH(5, 0, gC, HIPEIG_BLOCK, 0, tc, 0);
       }
       hipeig_phase_mark(c, 3);
       return 0;
