@@ -30,6 +30,7 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+_T_START = time.time()
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0   # same guide: measured float4 copy (79 % of spec)
@@ -153,37 +154,38 @@ def main(result):
                 "why": "HIPEIG_COMM=" + comm_mode if comm_mode != "auto" else "direct exchange unavailable (see stderr)"}
 
     exchange = None
-    if world > 1 and "HIPEIG_GATHER_CHUNKS" not in os.environ:
-        # How many chunks the operand exchange is cut into is a property of the operator's column layout, so the choice is
-        # made by building the operator both ways (one chunk: two sweep launches; two chunks: the first chunk's windows run
-        # while the second travels), letting each pick its exchange backend, timing 10 products, and keeping the faster.
-        trials = []
+    if world > 1 and os.environ.get("HIPEIG_BENCH_CHUNK_TRIALS", "0") not in ("", "0") and "HIPEIG_GATHER_CHUNKS" not in os.environ:
+        # Experiment mode (off by default: it doubles the start-up of every rank): build the operator with one and with
+        # two exchange chunks, let each pick its exchange backend, time 10 products, keep the faster.  Only the timings
+        # of the losing build are kept, not the build.
+        tried = {}
         for nch in (1, 2):
             ctx.set_gather_chunks(nch)
-            Hn, tg = make_operator()
-            ex = pick_exchange(Hn)
+            Hn, _ = make_operator()
+            pick_exchange(Hn)
             for _ in range(3):
                 Hn.apply_shifted(a.sigma, x._buf, y)
             barrier()
             ctx.timer_start()
             for _ in range(10):
                 Hn.apply_shifted(a.sigma, x._buf, y)
-            ms = allmax(ctx.timer_stop() / 10)
-            trials.append((ms, nch, Hn, tg, ex))
+            tried[nch] = allmax(ctx.timer_stop() / 10)
             del Hn
-        trials.sort(key=lambda t: t[0])
-        ms_best, nch_best, H, t_gen, exchange = trials[0]
-        exchange = dict(exchange, chunks_tried={str(t[1]): round(t[0], 4) for t in trials}, chunks_chosen=nch_best)
+            ctx.synchronize()
+        nch_best = min(tried, key=tried.get)
         ctx.set_gather_chunks(nch_best)
-        ctx.set_gather_backend(exchange["chosen"])
-        ctx.set_allreduce_backend(exchange["allreduce_chosen"])
-        del trials
+        H, t_gen = make_operator()
+        exchange = dict(pick_exchange(H), chunks_tried={str(k): round(v, 4) for k, v in tried.items()}, chunks_chosen=nch_best)
     else:
+        # The number of exchange chunks follows from the layout (the library's rule: two when a rank's slice spans >= 8
+        # column windows, so that the first chunk's windows are swept while the second travels; HIPEIG_GATHER_CHUNKS
+        # overrides); ONE operator build per rank, then only the exchange backends are timed (5 + 10 products each).
         H, t_gen = make_operator()
         if world > 1:
             exchange = pick_exchange(H)
     nnz_total = int(allsum(float(H.nnz)))
 
+    startup_s = time.time() - _T_START                # process start -> first warm-up product (imports, rendezvous, build, backend choice)
     for _ in range(a.warmup):
         H.apply_shifted(a.sigma, x._buf, y)
     barrier()
@@ -221,6 +223,26 @@ def main(result):
             phases[k] = round(v, 5) if v >= 0 else None
         phases["allreduce_ms"] = round(allmax(ctx.allreduce_ms(2, 50)), 5)
         phases["exchange_chunks"] = H.layout_info()["exchange_chunks"]
+        # One rank's sweeps ALONE on its device, exchange switched off (own slice placed, peers' parts stale): the compute
+        # part of the product.  On a real node every rank has its own GPU and this equals local + remote sweep; in a
+        # rehearsal with several ranks on ONE GPU the ranks take turns (host barrier between them), which separates the
+        # cost of the split sweep from the cost of sharing the GPU.
+        if world > 1:
+            tg = D.tcp_group(rank, world)
+            alone = -1.0
+            for r in range(world):
+                tg.barrier()
+                if r == rank:
+                    ctx.set_exchange(False)
+                    for _ in range(2):
+                        H.apply_shifted(a.sigma, x._buf, y)
+                    ctx.timer_start()
+                    for _ in range(10):
+                        H.apply_shifted(a.sigma, x._buf, y)
+                    alone = ctx.timer_stop() / 10
+                    ctx.set_exchange(True)
+            tg.barrier()
+            phases["sweeps_alone_ms"] = round(allmax(alone), 5)
 
     # what a plain streaming kernel reaches on THIS device (confirm the nominal figure on the
     # box): out-of-place scale of 1e8 doubles, 0.8 GB read + 0.8 GB written per call, well past the Infinity Cache
@@ -270,7 +292,8 @@ def main(result):
                                f"row-partitioned over {world} GPU(s)",
                    "N": N, "nnz": nnz_total, "nnz_per_row": round(nnz_total / N, 3), "nnz_row_arg": a.nnz_row, "sigma": a.sigma,
                    "kernel_variant": ("auto:" if a.variant == 0 else "forced:") + H.last_variant(),
-                   "generator_seed": a.seed, "generate_s": round(t_gen, 2), "rccl_library": rccl_lib,
+                   "generator_seed": a.seed, "generate_s": round(t_gen, 2), "startup_s": round(allmax(startup_s), 2),
+                   "rccl_library": rccl_lib,
                    "comm": comm_mode, "exchange": exchange, "layout": H.layout_info()},
         "roofline": {"bound": "hbm", "kernel": kname,
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

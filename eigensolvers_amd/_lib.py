@@ -42,6 +42,8 @@ SIGNATURES = {
     "hipeig_comm_set_allreduce_backend": [_P, C.c_int],
     "hipeig_direct_alloc": [_P, _I64, _P],
     "hipeig_direct_attach": [_P, _P],
+    "hipeig_direct_release": [_P],
+    "hipeig_comm_set_exchange": [_P, C.c_int],
     "hipeig_comm_set_gather_backend": [_P, C.c_int],
     "hipeig_comm_gather_info": [_P, _I64P],
     "hipeig_comm_set_gather_chunks": [_P, C.c_int],

@@ -36,7 +36,7 @@ static int finalize_to_host(hipeig_ctx* c, int nblocks, int ncols, double* host_
     hipLaunchKernelGGL(finalize_kernel, dim3(ncols), dim3(HIPEIG_BLOCK), 0, c->stream,
                        c->d_partials, nblocks, ncols, c->h_scalars_dev);
     HIPEIG_CHECK(hipGetLastError());
-    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+    if (hipeig_sync_checked(c)) return 4;
     memcpy(host_out, c->h_scalars, sizeof(double) * ncols);
     return 0;
   }
@@ -47,7 +47,7 @@ static int finalize_to_host(hipeig_ctx* c, int nblocks, int ncols, double* host_
   if (host_out) {
     HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(double) * ncols,
                                 hipMemcpyDeviceToHost, c->stream));
-    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+    if (hipeig_sync_checked(c)) return 4;
     memcpy(host_out, c->h_scalars, sizeof(double) * ncols);
   }
   return 0;
@@ -96,13 +96,13 @@ extern "C" int hipeig_dot(hipeig_ctx* c, int64_t n, const double* x, const doubl
                      direct ? c->h_scalars_dev : c->d_scalars);
   HIPEIG_CHECK(hipGetLastError());
   if (direct) {
-    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+    if (hipeig_sync_checked(c)) return 4;
     *out = c->h_scalars[0];
     return 0;
   }
   if (hipeig_allreduce_sum(c, c->d_scalars, 1)) return 4;
   HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  if (hipeig_sync_checked(c)) return 4;
   *out = c->h_scalars[0];
   return 0;
 }
@@ -317,7 +317,7 @@ extern "C" int hipeig_lincomb_block(hipeig_ctx* c, int64_t n, int m, int k, cons
     const int kk = (k - c0 < HIPEIG_MAX_COLS) ? (k - c0) : HIPEIG_MAX_COLS;
     const int KB = kk <= 4 ? 4 : kk <= 8 ? 8 : HIPEIG_MAX_COLS;
     if (cf_used + (size_t)m * KB > c->scalars_doubles) {            // staging area full: wait for the copies issued so far
-      HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+      if (hipeig_sync_checked(c)) return 4;
       cf_used = 0;
     }
     HIPEIG_REQUIRE((size_t)m * KB <= c->scalars_doubles, "too many input vectors for the coefficient staging buffer");
@@ -734,7 +734,7 @@ extern "C" int hipeig_mgs_project(hipeig_ctx* c, int64_t n, int m, const double*
   }
   HIPEIG_CHECK(hipGetLastError());
   HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dcoef, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  if (hipeig_sync_checked(c)) return 4;
   memcpy(coeffs, c->h_scalars, sizeof(double) * m);
   return 0;
 }
@@ -760,7 +760,7 @@ extern "C" int hipeig_pair_mgs_project(hipeig_ctx* c, int64_t n, int m, const do
   }
   HIPEIG_CHECK(hipGetLastError());
   HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dcoef, sizeof(double) * 2 * m, hipMemcpyDeviceToHost, c->stream));
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  if (hipeig_sync_checked(c)) return 4;
   memcpy(coeffs, c->h_scalars, sizeof(double) * 2 * m);
   return 0;
 }
@@ -1383,7 +1383,7 @@ extern "C" int hipeig_arnoldi_step(hipeig_ctx* c, int64_t n, int m, const double
     const bool direct = c->h_scalars_dev && arnoldi_is_small(n, m);     // no copy to wait for: 28 -> 17 us per step
     if (arnoldi_fused<false>(c, n, m, V, nullptr, w, nullptr, direct ? c->h_scalars_dev : dres)) return 4;
     if (!direct) HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dres, sizeof(double) * (m + 2), hipMemcpyDeviceToHost, c->stream));
-    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+    if (hipeig_sync_checked(c)) return 4;
     memcpy(out, c->h_scalars, sizeof(double) * (m + 2));
     return 0;
   }
@@ -1403,7 +1403,7 @@ extern "C" int hipeig_arnoldi_step(hipeig_ctx* c, int64_t n, int m, const double
   hipLaunchKernelGGL(scale_by_inv_norm_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, dres + 1 + m, w, (double*)nullptr);
   HIPEIG_CHECK(hipGetLastError());
   HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dres, sizeof(double) * (m + 2), hipMemcpyDeviceToHost, c->stream));
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  if (hipeig_sync_checked(c)) return 4;
   memcpy(out, c->h_scalars, sizeof(double) * (m + 2));
   return 0;
 }
@@ -1418,7 +1418,7 @@ extern "C" int hipeig_pair_arnoldi_step(hipeig_ctx* c, int64_t n, int m, const d
     const bool direct = c->h_scalars_dev && arnoldi_is_small(n, m);
     if (arnoldi_fused<true>(c, n, m, Vre, Vim, wre, wim, direct ? c->h_scalars_dev : dres)) return 4;
     if (!direct) HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dres, sizeof(double) * (2 * m + 2), hipMemcpyDeviceToHost, c->stream));
-    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+    if (hipeig_sync_checked(c)) return 4;
     memcpy(out, c->h_scalars, sizeof(double) * (2 * m + 2));
     return 0;
   }
@@ -1439,7 +1439,7 @@ extern "C" int hipeig_pair_arnoldi_step(hipeig_ctx* c, int64_t n, int m, const d
   hipLaunchKernelGGL(scale_by_inv_norm_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, dres + 1 + 2 * m, wre, wim);
   HIPEIG_CHECK(hipGetLastError());
   HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dres, sizeof(double) * (2 * m + 2), hipMemcpyDeviceToHost, c->stream));
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  if (hipeig_sync_checked(c)) return 4;
   memcpy(out, c->h_scalars, sizeof(double) * (2 * m + 2));
   return 0;
 }
@@ -1455,7 +1455,7 @@ extern "C" int hipeig_arnoldi_step_p(hipeig_ctx* c, int64_t n, int m, const doub
   double* dres = c->d_scalars + 2560;                  // m + 2 doubles (< 640: the total records sit at 3200)
   if (arnoldi_blocked<false>(c, n, m, V, nullptr, w, nullptr, dres)) return 4;
   HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dres, sizeof(double) * (m + 2), hipMemcpyDeviceToHost, c->stream));
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  if (hipeig_sync_checked(c)) return 4;
   memcpy(out, c->h_scalars, sizeof(double) * (m + 2));
   return 0;
 }
@@ -1469,7 +1469,7 @@ extern "C" int hipeig_pair_arnoldi_step_p(hipeig_ctx* c, int64_t n, int m, const
   double* dres = c->d_scalars + 2560;                  // 2m + 2 doubles (< 640: the total records sit at 3200)
   if (arnoldi_blocked<true>(c, n, m, Vre, Vim, wre, wim, dres)) return 4;
   HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dres, sizeof(double) * (2 * m + 2), hipMemcpyDeviceToHost, c->stream));
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  if (hipeig_sync_checked(c)) return 4;
   memcpy(out, c->h_scalars, sizeof(double) * (2 * m + 2));
   return 0;
 }

@@ -393,7 +393,8 @@ int hipeig_comm_setup_rows(hipeig_ctx* c, int64_t nrows_local, GatherLayout* gl)
     HIPEIG_CHECK(hipMemsetAsync(c->x_full, 0, (size_t)need * sizeof(double), c->stream));
     c->x_full_n = need;
   }
-  if (c->direct && hipeig_direct_reserve(c, need)) return 4;
+  // the direct buffers must hold the operand only where they are (or will be, checked at the switch) the ones in use
+  if (hipeig_direct_ready(c) && c->gather_backend == 1 && hipeig_direct_reserve(c, need)) return 4;
   return 0;
 }
 
@@ -429,6 +430,7 @@ int hipeig_allgather_x_begin(hipeig_ctx* c, const GatherLayout& gl, const double
       HIPEIG_CHECK(hipMemcpyAsync(buf + gl.pos(c->rank, lo), x_local + lo, (size_t)(hi - lo) * sizeof(double),
                                   hipMemcpyDeviceToDevice, c->stream));
   }
+  if (c->exchange_off) return 0;                             // measurement aid: the peers' parts keep their previous values
   HIPEIG_CHECK(hipEventRecord(c->ev_x, c->stream));
   HIPEIG_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_x, 0));
   phase_mark(c, 4, c->comm_stream);
@@ -447,6 +449,7 @@ int hipeig_allgather_x_begin(hipeig_ctx* c, const GatherLayout& gl, const double
 
 // The compute stream waits until chunk `chunk` (and every earlier one) of the exchange begun last has arrived.
 int hipeig_allgather_x_wait_chunk(hipeig_ctx* c, const GatherLayout& gl, int chunk) {
+  if (c->exchange_off) return 0;
   if (c->direct && c->gather_backend == 1) return hipeig_direct_wait_chunk(c, gl, chunk);
   HIPEIG_CHECK(hipStreamWaitEvent(c->stream, c->ev_chunk[chunk], 0));
   return 0;
@@ -526,6 +529,17 @@ double* hipeig_gather_block_slot(hipeig_ctx* c, const GatherLayout& gl, int K) {
 
 // Chunks of the operand exchange for operators created FROM NOW ON (0 = automatic, pick_gather_chunks); existing operators
 // keep the layout their columns were remapped to.  Every rank must set the same value.
+// Measurement aid: on = 0 makes the products of this context place their own slice in the gathered buffer and skip the
+// exchange with the peers (whose parts keep the values of the last real exchange), so that ONE rank's sweeps - own
+// windows + remaining windows, the compute part of a partitioned product - can be timed alone on a shared GPU.
+// Results are meaningless while it is off.  Not collective; switch it back on before the next collective product.
+extern "C" int hipeig_comm_set_exchange(hipeig_ctx* c, int on) {
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  HIPEIG_CHECK(hipStreamSynchronize(c->comm_stream));
+  c->exchange_off = on ? 0 : 1;
+  return 0;
+}
+
 extern "C" int hipeig_comm_set_gather_chunks(hipeig_ctx* c, int nchunks) {
   HIPEIG_REQUIRE(nchunks >= 0 && nchunks <= HIPEIG_GATHER_MAX_CHUNKS, "chunks must be 0 (automatic) .. 4");
   c->gather_chunks = nchunks;

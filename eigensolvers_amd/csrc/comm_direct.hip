@@ -30,7 +30,7 @@
 // fine-grained area of a rank, in 8-byte words: arrival flags of the exchange, flags of the mailboxes, the mailboxes
 #define DIRECT_MBOX_OFFSET (DIRECT_GATHER_FLAGS + DIRECT_MBOX_FLAGS)
 #define DIRECT_FLAG_WORDS (DIRECT_MBOX_OFFSET + 2 * HIPEIG_MAX_RANKS * DIRECT_MBOX_DOUBLES)
-#define DIRECT_WAIT_LIMIT_S 60
+#define DIRECT_WAIT_LIMIT_S 120                        // HIPEIG_DIRECT_WAIT_S: the skew between ranks a wait tolerates
 
 struct DirectComm {
   int nranks, rank;
@@ -217,6 +217,8 @@ extern "C" int hipeig_comm_set_gather_backend(hipeig_ctx* c, int backend) {
   HIPEIG_REQUIRE(backend == 0 || backend == 1, "backend must be 0 (RCCL) or 1 (direct)");
   HIPEIG_REQUIRE(backend == 0 || (c->direct && c->direct->attached), "the direct exchange is not attached");
   HIPEIG_REQUIRE(backend == 1 || c->comm || c->loop, "no RCCL communicator to switch to");
+  HIPEIG_REQUIRE(backend == 0 || c->x_full_n <= c->direct->capacity,
+                 "the direct exchange buffers are smaller than the gathered operand of an existing operator");
   HIPEIG_CHECK(hipStreamSynchronize(c->stream));
   HIPEIG_CHECK(hipStreamSynchronize(c->comm_stream));
   c->gather_backend = backend;
@@ -401,3 +403,17 @@ int hipeig_direct_allreduce(hipeig_ctx* c, double* buf, int64_t count, hipStream
 }
 
 bool hipeig_direct_ready(const hipeig_ctx* c) { return c->direct && c->direct->attached; }
+
+int hipeig_sync_checked(hipeig_ctx* c) {
+  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  if (c->direct && c->direct->h_err && *c->direct->h_err) {
+    hipeig_set_error("direct exchange: the data of rank %d did not arrive within the wait limit (HIPEIG_DIRECT_WAIT_S); "
+                     "results computed since are invalid", *c->direct->h_err - 1);
+    return 4;
+  }
+  return 0;
+}
+
+// Release the buffers of the direct exchange (a collective fall-back to RCCL would otherwise keep two gathered operands
+// per rank allocated for nothing).
+extern "C" int hipeig_direct_release(hipeig_ctx* c) { return hipeig_direct_destroy(c); }

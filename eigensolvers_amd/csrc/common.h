@@ -130,6 +130,7 @@ struct hipeig_ctx {
   struct DirectComm* direct;
   int gather_backend;        // operand exchange: 0 = RCCL (or loopback), 1 = direct peer writes
   int allreduce_backend;     // small (<= 1024 doubles) all-reduces: 0 = RCCL, 1 = the peers' mailboxes (comm_direct.hip)
+  int exchange_off;          // measurement aid (hipeig_comm_set_exchange): products place the own slice and skip the exchange
 };
 
 struct hipeig_csr {
@@ -180,6 +181,10 @@ struct hipeig_csr {
   int64_t col_stride;        // > 0 when the columns were remapped to the gathered layout `gl` (= gl.h); 0 = global columns
   int64_t bytes;
 };
+
+// Synchronise the compute stream and report a direct-exchange wait that gave up (comm_direct.hip): every path that hands
+// a result to the host goes through this, so a timed-out wait is an error of THAT call, not of some later one.
+int hipeig_sync_checked(hipeig_ctx* c);
 
 // ---- collectives (comm.hip); no-ops without a communicator ---------------------------
 int hipeig_comm_setup_rows(hipeig_ctx* ctx, int64_t nrows_local, GatherLayout* gl_out);

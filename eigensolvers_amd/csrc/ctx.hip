@@ -107,7 +107,7 @@ extern "C" int hipeig_ctx_destroy(hipeig_ctx* c) {
 }
 
 extern "C" int hipeig_ctx_sync(hipeig_ctx* c) {
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  if (hipeig_sync_checked(c)) return 4;
   return 0;
 }
 
@@ -143,20 +143,20 @@ extern "C" int hipeig_vec_alloc(hipeig_ctx* c, int64_t n, double** out) {
 extern "C" int hipeig_vec_free(hipeig_ctx* c, double* v) {
   if (!v) return 0;
   // pending kernels on the compute stream may still read v
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  if (hipeig_sync_checked(c)) return 4;
   HIPEIG_CHECK(hipFree(v));
   return 0;
 }
 
 extern "C" int hipeig_vec_upload(hipeig_ctx* c, double* dst, const double* src, int64_t n) {
   HIPEIG_CHECK(hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  if (hipeig_sync_checked(c)) return 4;
   return 0;
 }
 
 extern "C" int hipeig_vec_download(hipeig_ctx* c, double* dst, const double* src, int64_t n) {
   HIPEIG_CHECK(hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  if (hipeig_sync_checked(c)) return 4;
   return 0;
 }
 

@@ -313,7 +313,7 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
   MinresState* V = c->d_mr_state;
   HIPEIG_CHECK(hipMemcpyAsync(V, h, sizeof(MinresState), hipMemcpyHostToDevice, c->stream));
   // the pinned record is rewritten by the first chunk's copy-back; the upload above must have read it
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+  if (hipeig_sync_checked(c)) return 4;
 
   int variant = hipeig_csr_pick_variant(c, A);
   if (variant < 0) return 1;
@@ -537,7 +537,7 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
       HIPEIG_CHECK(hipGraphLaunch(c->mr_graph, c->stream));
       GTRACE("hipGraphLaunch returned");
       if (!graph_copy_node) HIPEIG_CHECK(hipMemcpyAsync(h, V, sizeof(MinresState), hipMemcpyDeviceToHost, c->stream));
-      HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+      if (hipeig_sync_checked(c)) return 4;
       if (h->done) break;
     }
   } else {
@@ -564,7 +564,7 @@ extern "C" int hipeig_minres_x0(hipeig_ctx* c, hipeig_csr* A, double sigma, doub
         HIPEIG_CHECK(hipGetLastError());
         if (enqueue_check()) return 1;
       }
-      HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+      if (hipeig_sync_checked(c)) return 4;
       if (h->done) break;
     }
   }

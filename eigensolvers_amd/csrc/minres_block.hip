@@ -286,7 +286,7 @@ static int minres_block_impl(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   HIPEIG_CHECK(hipMemsetAsync(R[1], 0, (size_t)c->mrb_ws_n * 6 * sizeof(double), c->stream));
   MinresState* V = c->d_mrb_state;
   HIPEIG_CHECK(hipMemcpyAsync(V, h, K * sizeof(MinresState), hipMemcpyHostToDevice, c->stream));
-  HIPEIG_CHECK(hipStreamSynchronize(c->stream));       // the pinned records are rewritten by the first copy-back
+  if (hipeig_sync_checked(c)) return 4;       // the pinned records are rewritten by the first copy-back
 
   const int bv = hipeig_block_pick_variant(c, A, K);
   if (bv < 0) return 1;
@@ -415,7 +415,7 @@ static int minres_block_impl(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
       hipLaunchKernelGGL(minres_block_check_kernel<K>, dim3(1), dim3(HIPEIG_BLOCK), 0, c->stream, ac, V + 0);
       HIPEIG_CHECK(hipMemcpyAsync(h, V, K * sizeof(MinresState), hipMemcpyDeviceToHost, c->stream));
     }
-    HIPEIG_CHECK(hipStreamSynchronize(c->stream));
+    if (hipeig_sync_checked(c)) return 4;
     all_done = true;
     for (int j = 0; j < K; ++j) all_done = all_done && h[j].done;
   }

@@ -336,6 +336,10 @@ def enable_direct_gather(ctx, capacity_doubles, rank=None, world=None):
         return True
     if err:
         print(f"[hipeig rank {rank}] direct exchange unavailable ({err}); staying on RCCL", file=sys.stderr)
+    try:
+        ctx.direct_release()            # a rank that did succeed would keep two gathered operands allocated for nothing
+    except Exception:                   # noqa: BLE001 - nothing was allocated
+        pass
     return False
 
 
@@ -387,16 +391,23 @@ def choose_gather_backend(ctx, H, group, reps=5):
     same = group.allmax(0.0 if same else 1.0) == 0.0
     pick = "direct" if (same and times["direct"] < times["rccl"]) else "rccl"
     ctx.set_gather_backend(pick)
-    # the small all-reduce of a MINRES iteration (two doubles), same choice by the same rule
-    ar = {}
+    # the small all-reduce of a MINRES iteration (two doubles): same choice by the same rule, with its OWN result check -
+    # a known record ((rank + 1) * (1 .. 16), several rounds so that both mailboxes are used) summed through each backend
+    ar, ar_ok = {}, True
+    want = np.arange(1.0, 17.0) * (ctx.nranks * (ctx.nranks + 1) / 2.0)
     for name in ("rccl", "direct"):
         ctx.set_allreduce_backend(name)
+        for rnd in range(4):
+            rec = HipVector((ctx.rank + 1.0) * np.arange(1.0, 17.0) * (rnd + 1), ctx=ctx)
+            ctx.allreduce_vector(rec._buf)
+            ar_ok = ar_ok and bool(np.array_equal(rec.array, want * (rnd + 1)))      # small integers: exact in any order
         ar[name] = group.allmax(ctx.allreduce_ms(2, 50))
-    pick_ar = "direct" if (same and ar["direct"] < ar["rccl"]) else "rccl"
+    ar_ok = group.allmax(0.0 if ar_ok else 1.0) == 0.0
+    pick_ar = "direct" if (same and ar_ok and ar["direct"] < ar["rccl"]) else "rccl"
     ctx.set_allreduce_backend(pick_ar)
     return {"rccl_ms": round(times["rccl"], 4), "direct_ms": round(times["direct"], 4), "results_agree": same,
             "products_compared": 2 * reps, "chosen": pick, "reps": reps, "allreduce_rccl_ms": round(ar["rccl"], 4),
-            "allreduce_direct_ms": round(ar["direct"], 4), "allreduce_chosen": pick_ar}
+            "allreduce_direct_ms": round(ar["direct"], 4), "allreduce_results_agree": ar_ok, "allreduce_chosen": pick_ar}
 
 
 class DeviceGroup:

@@ -93,6 +93,15 @@ class HipContext:
         buf = C.create_string_buffer(blob, len(blob))
         _lib.call("hipeig_direct_attach", self.handle, C.cast(buf, C.c_void_p))
 
+    def direct_release(self):
+        """Free the buffers of the direct exchange (after a collective fall-back to RCCL)."""
+        _lib.call("hipeig_direct_release", self.handle)
+
+    def set_exchange(self, on):
+        """Measurement aid: ``False`` makes this context's products skip the operand exchange (own slice only; results
+        meaningless) so that one rank's sweeps can be timed alone; switch back before the next collective product."""
+        _lib.call("hipeig_comm_set_exchange", self.handle, 1 if on else 0)
+
     def attach_direct_only(self, nranks, rank):
         """A communicator without RCCL (rank / size only): every exchange goes through the direct peer-write backend,
         which must be attached before the first operator is created (``distributed.attach_direct``)."""

@@ -74,11 +74,14 @@ int hipeig_vec_allreduce(hipeig_ctx* ctx, double* v, int64_t n);
  * side all-gathers the records of all ranks in rank order (eigensolvers_amd.distributed) and hands them to
  * hipeig_direct_attach; hipeig_comm_set_gather_backend then switches (every rank at the same point, nothing in flight).
  * hipeig_comm_gather_info: info[0] backend, [1] attached, [2] capacity, [3] exchanges begun, [4] error word of the
- * bounded waits (0 = none), [5] HIPEIG_GATHER_CHUNKS override (0 = automatic).                                        */
+ * bounded waits (0 = none), [5] HIPEIG_GATHER_CHUNKS override (0 = automatic).  A wait that gave up (HIPEIG_DIRECT_WAIT_S,
+ * default 120 s: the skew between ranks it tolerates) makes the NEXT call that returns anything to the host - dot, nrm2,
+ * the solvers, downloads, hipeig_ctx_sync - fail with rc 4; the error sticks to the context.                           */
 int hipeig_comm_init_direct(hipeig_ctx* ctx, int nranks, int rank);   /* rank / size without RCCL: every exchange direct */
 int hipeig_comm_set_allreduce_backend(hipeig_ctx* ctx, int backend);  /* small all-reduces: 0 RCCL, 1 the peers' mailboxes */
 int hipeig_direct_alloc(hipeig_ctx* ctx, int64_t capacity_doubles, void* record192_out);
 int hipeig_direct_attach(hipeig_ctx* ctx, const void* all_records /* nranks x 192 bytes */);
+int hipeig_direct_release(hipeig_ctx* ctx);    /* frees the direct buffers again (after a collective fall-back to RCCL) */
 int hipeig_comm_set_gather_backend(hipeig_ctx* ctx, int backend);
 int hipeig_comm_gather_info(hipeig_ctx* ctx, int64_t info[8]);
 /* chunks of the operand exchange (1-4; 0 = automatic) for operators created from now on; the same on every rank */
@@ -88,6 +91,9 @@ int hipeig_comm_set_gather_chunks(hipeig_ctx* ctx, int nchunks);
  * windows incl. waits for later chunks, [3] whole product, [4] compute stream idle before the first chunk arrived;
  * and the average time of `reps` back-to-back all-reduces of `count` doubles.                                          */
 int hipeig_phase_timing(hipeig_ctx* ctx, int on);
+/* on = 0: products of this context place their own slice and SKIP the exchange (results meaningless) - times one rank's
+ * sweeps alone on a shared GPU; not collective, switch back on before the next collective product                     */
+int hipeig_comm_set_exchange(hipeig_ctx* ctx, int on);
 int hipeig_phase_get(hipeig_ctx* ctx, double out[8]);
 int hipeig_comm_bench_allreduce(hipeig_ctx* ctx, int count, int reps, double* ms_each);
 int hipeig_loopback_group_create(int nranks, void** group_out);

@@ -22,7 +22,7 @@ def _clean_env():
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("n", [2, 3])
+@pytest.mark.parametrize("n", [2, 3, 8])                 # 8: the command line of a SCALE run, `python bench.py --gpus 8`
 def test_plain_start_spawns_the_ranks_and_relays_rank0(n):
     r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--rendezvous-only"], capture_output=True, text=True,
                        env=_clean_env(), timeout=150)
