@@ -18,31 +18,111 @@ struct CoefTable {
   double c[HIPEIG_MAX_COLS];
 };
 
-// ---- stage-2 reduction: out[j] = sum_b partials[b*ncols + j] ---------------------------
-__global__ void finalize_kernel(const double* __restrict__ partials, int nblocks, int ncols,
-                                double* __restrict__ out) {
-  __shared__ double lds[4];
-  const int j = blockIdx.x;
+// ---- reductions of RECORDS that finish inside the kernel that produces them ------------------------------------------
+// multi_dot (one value per column), the MGS pair of dots, a Gram block (up to 1024 elements): every workgroup leaves a
+// record of nv values, and the totals are formed without a second launch (round 3 did this for single scalars, common.h):
+//   * workgroup b stores its record at partials[b * nv ..] (agent-scope stores, waited for) and takes a ticket of its
+//     GROUP of 64 workgroups;
+//   * the workgroup that completes a group adds the group's <= 64 records in ascending order into a group record and takes
+//     a ticket of the master counter; the one that completes the master adds the <= 32 group records in order and stores
+//     the totals (to mapped host memory on one GPU: a stream wait, no copy).
+// Two levels because one workgroup adding 2048 records of 1 KiB would take longer than the launch it replaces; the group
+// sums run on as many CUs as there are groups.  Order and tree are fixed by (gridDim.x, nv): bitwise reproducible.
+#define REC_GROUP 64
+#define REC_MAX_GROUPS 32
+#define REC_MAX_VALUES 1024
+
+__device__ __forceinline__ double agent_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void agent_store_nowait(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// sum_{i = first, first + step, ... < count} p[i * nv]: loads in batches of 8 (all in flight), adds in index order
+__device__ __forceinline__ double agent_sum_strided(const double* p, int first, int count, int step, size_t nv) {
   double a = 0.0;
-  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) a += partials[(size_t)b * ncols + j];
-  a = block_reduce_sum(a, lds);
-  if (threadIdx.x == 0) out[j] = a;
+  int i = first;
+  for (; i + 7 * step < count; i += 8 * step) {
+    double t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t[q] = agent_load(p + (size_t)(i + q * step) * nv);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a += t[q];
+  }
+  for (; i < count; i += step) a += agent_load(p + (size_t)i * nv);
+  return a;
 }
 
-static int finalize_to_host(hipeig_ctx* c, int nblocks, int ncols, double* host_out) {
+// Totals of `count` records of nv values (record-major) by ONE 256-thread workgroup; store(e, total_e) is called once per
+// value.  nv <= 128: 256 / nvp lanes share a value (nvp = nv rounded up to a power of two), their sums are added in lane
+// order through LDS; larger records: one thread per value, 256 values at a time.  lds: 256 doubles.
+template <class Store>
+__device__ __forceinline__ void sum_records(const double* p, int count, int nv, double* lds, Store store) {
+  const int t = threadIdx.x;
+  if (nv <= 128) {
+    int nvp = 1;
+    while (nvp < nv) nvp <<= 1;
+    const int kl = HIPEIG_BLOCK / nvp, v = t & (nvp - 1), k = t / nvp;
+    lds[k * nvp + v] = (v < nv) ? agent_sum_strided(p + v, k, count, kl, (size_t)nv) : 0.0;
+    __syncthreads();
+    if (t < nv) {
+      double s = lds[t];
+      for (int q = 1; q < kl; ++q) s += lds[q * nvp + t];
+      store(t, s);
+    }
+    __syncthreads();
+  } else {
+    for (int e = t; e < nv; e += HIPEIG_BLOCK) store(e, agent_sum_strided(p + e, 0, count, 1, (size_t)nv));
+  }
+}
+
+// Call after every thread of the workgroup has issued the agent_store_nowait's of its share of the record
+// partials[blockIdx.x * nv ..].  counters: 1 + ceil(gridDim.x / 64) words, zero before the kernel and after it.
+__device__ __forceinline__ void finish_records(double* partials, double* group_partials, int nv, unsigned* counters,
+                                               double* lds /* 256 doubles */, double* out) {
+  __shared__ int sh_flag;
+  const unsigned G = gridDim.x, ng = (G + REC_GROUP - 1) / REC_GROUP, g = blockIdx.x / REC_GROUP;
+  const unsigned gsize = (g == ng - 1) ? G - g * REC_GROUP : REC_GROUP;
+  wait_for_my_stores();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const bool last = __hip_atomic_fetch_add(counters + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u;
+    if (last) __hip_atomic_store(counters + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_flag = last;
+  }
+  __syncthreads();
+  if (!sh_flag) return;                               // uniform
+  __syncthreads();
+  if (ng == 1) {
+    sum_records(partials, (int)G, nv, lds, [&](int e, double s) { out[e] = s; });
+    return;
+  }
+  double* mine = group_partials + (size_t)g * nv;
+  sum_records(partials + (size_t)g * REC_GROUP * nv, (int)gsize, nv, lds, [&](int e, double s) { agent_store_nowait(mine + e, s); });
+  wait_for_my_stores();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const bool last = __hip_atomic_fetch_add(counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1u;
+    if (last) __hip_atomic_store(counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_flag = last;
+  }
+  __syncthreads();
+  if (!sh_flag) return;
+  __syncthreads();
+  sum_records(group_partials, (int)ng, nv, lds, [&](int e, double s) { out[e] = s; });
+}
+
+// Where a record kernel stores its totals: the pinned, mapped host buffer when the caller wants them on the host of a
+// single-GPU context (the result then needs a stream wait but no copy command), else the device scalar area.
+static double* record_target(hipeig_ctx* c, bool to_host) {
+  return (to_host && !c->collectives && c->h_scalars_dev) ? c->h_scalars_dev : c->d_scalars;
+}
+
+// The totals are where record_target() said: sum them over the ranks if the context is partitioned and hand them over.
+static int records_to_host(hipeig_ctx* c, int ncols, double* host_out) {
+  HIPEIG_CHECK(hipGetLastError());
   if (host_out && !c->collectives && c->h_scalars_dev) {
-    // single GPU: the stage-2 kernel stores straight into the pinned host buffer (mapped into the
-    // device's address space), so the result needs a stream wait but no copy command
-    hipLaunchKernelGGL(finalize_kernel, dim3(ncols), dim3(HIPEIG_BLOCK), 0, c->stream,
-                       c->d_partials, nblocks, ncols, c->h_scalars_dev);
-    HIPEIG_CHECK(hipGetLastError());
     if (hipeig_sync_checked(c)) return 4;
     memcpy(host_out, c->h_scalars, sizeof(double) * ncols);
     return 0;
   }
-  hipLaunchKernelGGL(finalize_kernel, dim3(ncols), dim3(HIPEIG_BLOCK), 0, c->stream,
-                     c->d_partials, nblocks, ncols, c->d_scalars);
-  HIPEIG_CHECK(hipGetLastError());
   if (hipeig_allreduce_sum(c, c->d_scalars, ncols)) return 4;
   if (host_out) {
     HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(double) * ncols,
@@ -351,8 +431,8 @@ extern "C" int hipeig_multi_axpy(hipeig_ctx* c, int64_t n, int m, const double* 
 template <int MB>
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
 multi_dot_kernel(int64_t n, int m, PtrTable tab, const double* __restrict__ x,
-                 double* __restrict__ partials, int pstride) {
-  __shared__ double lds[4 * MB];
+                 double* __restrict__ partials, double* __restrict__ group_partials, unsigned* counters, double* __restrict__ out) {
+  __shared__ double lds[HIPEIG_BLOCK];
   double acc[MB];
 #pragma unroll
   for (int j = 0; j < MB; ++j) acc[j] = 0.0;
@@ -384,22 +464,24 @@ multi_dot_kernel(int64_t n, int m, PtrTable tab, const double* __restrict__ x,
   __syncthreads();
   if ((int)threadIdx.x < m) {
     const int j = threadIdx.x;
-    partials[(size_t)blockIdx.x * pstride + j] = lds[j] + lds[MB + j] + lds[2 * MB + j] + lds[3 * MB + j];
+    agent_store_nowait(partials + (size_t)blockIdx.x * m + j, lds[j] + lds[MB + j] + lds[2 * MB + j] + lds[3 * MB + j]);
   }
+  __syncthreads();                                   // lds is reused by the record sums
+  finish_records(partials, group_partials, m, counters, lds, out);
 }
 
-// partials laid out [block][pstride]; columns j0..j0+m of this launch go to offset j0.
-static int multi_dot_launch(hipeig_ctx* c, int64_t n, int m, const double* const* Y, const double* x,
-                            int g, int pstride, int poff) {
+// One launch for <= 16 columns: records [block][m] in the partial workspace (reused by the next launch: same stream),
+// totals to out[0..m).
+static int multi_dot_launch(hipeig_ctx* c, int64_t n, int m, const double* const* Y, const double* x, int g, double* out) {
   PtrTable tab;
   for (int j = 0; j < HIPEIG_MAX_COLS; ++j) tab.p[j] = (j < m) ? Y[j] : nullptr;
-  double* part = c->d_partials + poff;
+  unsigned* cnt = c->d_counters + 3 * HIPEIG_TICKET_WORDS;
   if (m <= 4)
-    hipLaunchKernelGGL((multi_dot_kernel<4>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, m, tab, x, part, pstride);
+    hipLaunchKernelGGL((multi_dot_kernel<4>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, m, tab, x, c->d_partials, c->d_group_partials, cnt, out);
   else if (m <= 8)
-    hipLaunchKernelGGL((multi_dot_kernel<8>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, m, tab, x, part, pstride);
+    hipLaunchKernelGGL((multi_dot_kernel<8>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, m, tab, x, c->d_partials, c->d_group_partials, cnt, out);
   else
-    hipLaunchKernelGGL((multi_dot_kernel<HIPEIG_MAX_COLS>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, m, tab, x, part, pstride);
+    hipLaunchKernelGGL((multi_dot_kernel<HIPEIG_MAX_COLS>), dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, m, tab, x, c->d_partials, c->d_group_partials, cnt, out);
   HIPEIG_CHECK(hipGetLastError());
   return 0;
 }
@@ -409,11 +491,12 @@ static int multi_dot_impl(hipeig_ctx* c, int64_t n, int m, const double* const* 
                           double* host_out) {
   HIPEIG_REQUIRE(m >= 1 && m <= HIPEIG_MAX_COLS * HIPEIG_MAX_COLS, "too many columns for one call");
   const int g = grid_for(n, 2);
+  double* target = record_target(c, host_out != nullptr);
   for (int j0 = 0; j0 < m; j0 += HIPEIG_MAX_COLS) {
     const int mm = (m - j0 < HIPEIG_MAX_COLS) ? (m - j0) : HIPEIG_MAX_COLS;
-    if (multi_dot_launch(c, n, mm, Y + j0, x, g, m, j0)) return 1;
+    if (multi_dot_launch(c, n, mm, Y + j0, x, g, target + j0)) return 1;
   }
-  return finalize_to_host(c, g, m, host_out);
+  return records_to_host(c, m, host_out);
 }
 
 extern "C" int hipeig_multi_dot(hipeig_ctx* c, int64_t n, int m, const double* const* Y,
@@ -438,8 +521,8 @@ extern "C" int hipeig_multi_dot(hipeig_ctx* c, int64_t n, int m, const double* c
 // as K-steps of 4.  LDS column stride 130 doubles (= 2 mod 32): the 32 lanes of an operand read
 // (16 columns x 2 rows) hit 32 distinct 8-byte banks.  Two workgroups per CU overlap one's loads with
 // the other's MFMAs.  Traffic: every column is read once per pass, (ma + mb) * 8N bytes against
-// 8N * ma * (mb + 1) for mb multi_dot sweeps.  Per-workgroup partial blocks are summed by
-// finalize_kernel in fixed order, like every other reduction.
+// 8N * ma * (mb + 1) for mb multi_dot sweeps.  Per-workgroup partial blocks are summed in fixed order
+// by the kernel's own last workgroups (finish_records above).
 typedef double d4_t __attribute__((ext_vector_type(4)));
 #define GRAM_ROWS 128
 #define GRAM_LD 130
@@ -451,7 +534,8 @@ struct PtrTable32 {
 
 template <int NA, int NB, bool SAME>
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
-gram_tile_kernel(int64_t n, int ma, int mb, PtrTable32 A, PtrTable32 B, double* __restrict__ partials) {
+gram_tile_kernel(int64_t n, int ma, int mb, PtrTable32 A, PtrTable32 B, double* __restrict__ partials,
+                 double* __restrict__ group_partials, unsigned* counters, double* __restrict__ out) {
   extern __shared__ double gram_lds[];
   constexpr int CA = NA * 16, CB = SAME ? 0 : NB * 16;
   double* tA = gram_lds;
@@ -529,8 +613,10 @@ gram_tile_kernel(int64_t n, int ma, int mb, PtrTable32 A, PtrTable32 B, double* 
   for (int blk = 0; blk < NA * NB; ++blk) {
     const double v = red[(0 * NA * NB + blk) * 256 + e] + red[(1 * NA * NB + blk) * 256 + e] +
                      red[(2 * NA * NB + blk) * 256 + e] + red[(3 * NA * NB + blk) * 256 + e];
-    partials[(size_t)blockIdx.x * (NA * NB * 256) + blk * 256 + e] = v;
+    agent_store_nowait(partials + (size_t)blockIdx.x * (NA * NB * 256) + blk * 256 + e, v);
   }
+  __syncthreads();                                   // the LDS block area is reused by the record sums
+  finish_records(partials, group_partials, NA * NB * 256, counters, gram_lds, out);
 }
 
 template <int NA, int NB, bool SAME>
@@ -553,7 +639,8 @@ static int gram_tile_launch(hipeig_ctx* c, int64_t n, int na, int nb, const PtrT
     HIPEIG_CHECK(hipFuncSetAttribute((const void*)gram_tile_kernel<NA, NB, SAME>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = true;
   }
-  hipLaunchKernelGGL((gram_tile_kernel<NA, NB, SAME>), dim3(g), dim3(HIPEIG_BLOCK), lds, c->stream, n, na, nb, ta, tb, c->d_partials);
+  hipLaunchKernelGGL((gram_tile_kernel<NA, NB, SAME>), dim3(g), dim3(HIPEIG_BLOCK), lds, c->stream, n, na, nb, ta, tb, c->d_partials,
+                     c->d_group_partials, c->d_counters + 3 * HIPEIG_TICKET_WORDS, record_target(c, true));
   HIPEIG_CHECK(hipGetLastError());
   return 0;
 }
@@ -599,7 +686,7 @@ extern "C" int hipeig_gram(hipeig_ctx* c, int64_t n, int ma, const double* const
       else if (NB == 1) rc = gram_tile_launch<2, 1, false>(c, n, na, nb, ta, tb, gl);
       else rc = gram_tile_launch<2, 2, false>(c, n, na, nb, ta, tb, gl);
       if (rc) return rc;
-      if (finalize_to_host(c, gl, NA * NB * 256, blk.data())) return 4;
+      if (records_to_host(c, NA * NB * 256, blk.data())) return 4;
       for (int i = 0; i < na; ++i)
         for (int j = 0; j < nb; ++j) {
           const int bi = i >> 4, bj = j >> 4;
@@ -618,8 +705,8 @@ extern "C" int hipeig_gram(hipeig_ctx* c, int64_t n, int ma, const double* const
 // reference MGS step (numpyVector.py:134-138): t1 = x.q and t2 = q.q in one sweep
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
 mgs_dots_kernel(int64_t n, const double* __restrict__ x, const double* __restrict__ q,
-                double* __restrict__ partials) {
-  __shared__ double lds[4];
+                double* __restrict__ partials, double* __restrict__ group_partials, unsigned* counters, double* __restrict__ out) {
+  __shared__ double lds[HIPEIG_BLOCK];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double a = 0.0, b = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -630,9 +717,10 @@ mgs_dots_kernel(int64_t n, const double* __restrict__ x, const double* __restric
   a = block_reduce_sum(a, lds);
   b = block_reduce_sum(b, lds);
   if (threadIdx.x == 0) {
-    partials[2 * blockIdx.x] = a;
-    partials[2 * blockIdx.x + 1] = b;
+    agent_store_nowait(partials + 2 * blockIdx.x, a);
+    agent_store_nowait(partials + 2 * blockIdx.x + 1, b);
   }
+  finish_records(partials, group_partials, 2, counters, lds, out);
 }
 
 // x <- 1.0*x + (-1.0)*(q*(t1/t2)): the reference's roundings, element by element
@@ -1547,9 +1635,9 @@ extern "C" int hipeig_orthonormalize(hipeig_ctx* c, int64_t n, int m, const doub
   if (method == 0) {
     const int g = grid_for(n, 4);
     for (int j = 0; j < m; ++j) {
-      hipLaunchKernelGGL(mgs_dots_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, x, Y[j], c->d_partials);
-      HIPEIG_CHECK(hipGetLastError());
-      if (finalize_to_host(c, g, 2, nullptr)) return 4;
+      hipLaunchKernelGGL(mgs_dots_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, x, Y[j], c->d_partials,
+                         c->d_group_partials, c->d_counters + 3 * HIPEIG_TICKET_WORDS, c->d_scalars);
+      if (records_to_host(c, 2, nullptr)) return 4;
       hipLaunchKernelGGL(mgs_update_kernel, dim3(grid_stream(n)), dim3(HIPEIG_BLOCK), 0, c->stream, n, c->d_scalars, Y[j], x);
       HIPEIG_CHECK(hipGetLastError());
     }

@@ -119,6 +119,7 @@ struct hipeig_ctx {
   int gather_chunks;         // chunks the operand all-gather is cut into (HIPEIG_GATHER_CHUNKS; 0 = automatic)
   hipEvent_t ev_chunk[HIPEIG_GATHER_MAX_CHUNKS];   // chunk c of the current all-gather has arrived (comm stream)
   unsigned* d_counters;      // arrival counters of the reductions that finish in their last workgroup (zero between kernels)
+  double* d_group_partials;  // group sums of the record reductions (blas1.hip, finish_records): 32 groups x 1024 values
   // phase timing of a partitioned product (hipeig_phase_timing): events on both streams
   int phase_timing;
   hipEvent_t ev_ph[8];

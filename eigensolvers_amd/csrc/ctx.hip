@@ -37,6 +37,7 @@ extern "C" int hipeig_ctx_create(int device, hipeig_ctx** out) {
   HIPEIG_CHECK(hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
   HIPEIG_CHECK(hipMalloc((void**)&c->d_counters, 4 * HIPEIG_TICKET_WORDS * sizeof(unsigned)));
   HIPEIG_CHECK(hipMemset(c->d_counters, 0, 4 * HIPEIG_TICKET_WORDS * sizeof(unsigned)));
+  HIPEIG_CHECK(hipMalloc((void**)&c->d_group_partials, (size_t)32 * 1024 * sizeof(double)));
   c->partials_doubles = (size_t)HIPEIG_MAX_PARTIALS * HIPEIG_MAX_COLS * HIPEIG_MAX_COLS * 2;   // 8 MiB
   HIPEIG_CHECK(hipMalloc((void**)&c->d_partials, c->partials_doubles * sizeof(double)));
   c->scalars_doubles = 4096;
@@ -100,6 +101,7 @@ extern "C" int hipeig_ctx_destroy(hipeig_ctx* c) {
   for (int k = 0; k < 16; ++k) hipEventDestroy(c->ev_slot[k]);
   hipEventDestroy(c->ev_stage);
   hipFree(c->d_counters);
+  hipFree(c->d_group_partials);
   hipStreamDestroy(c->stream);
   hipStreamDestroy(c->comm_stream);
   free(c);

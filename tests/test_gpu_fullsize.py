@@ -104,14 +104,15 @@ def test_config3_block8_lanczos_at_1e6(hip, op1e6, single_1e6):
     k = int(np.argmin(np.abs(ev[:8] - ev1[0])))
     assert abs(ev[k] - ev1[0]) <= 1e-10 * abs(ev1[0]), (ev[k], ev1[0])
     # the REAL reference on the same inputs (tests/golden/make_golden_r3.py config3: 8422 s of CPU): same number of cumulative
-    # iterations, the value next to sigma to the north-star tolerance, the whole block to 1e-9 (the outer block values are
-    # less converged in both runs: their true residuals are 1e-9 .. 4e-8)
+    # iterations, the value next to sigma AND the whole block to the north-star tolerance 1e-10 (the committed runs agree to
+    # 3e-13, profiles/r02b_configs_1_2_3.json; the outer block values are less converged in both runs - true residuals
+    # 1e-9 .. 4e-8 - which moves an eigenvalue by r^2 / gap ~ 1e-14 at most)
     g = _golden_json("config3_n1e6.json")
     assert g is not None and (g["L"], g["maxit"], g["eConv"], g["linear_tol"], g["nBlock"]) == \
         (BLOCK8_L, BLOCK8_MAXIT, BLOCK8_ECONV, BLOCK8_TOL, 8) and g["nnz"] == op1e6.nnz
     assert st["cumIter"] == g["cumIter"] and st["isConverged"] == g["isConverged"]
     ref8 = np.sort(np.array(g["ev"][:8]))
-    np.testing.assert_allclose(block, ref8, rtol=1e-9, atol=0)
+    np.testing.assert_allclose(block, ref8, rtol=1e-10, atol=0)
     assert abs(ev[k] - g["ev"][0]) <= 1e-10 * abs(g["ev"][0]), (ev[k], g["ev"][0])
     S = hip.HipVector.overlapMatrix(Y[:8])
     np.testing.assert_allclose(S, np.eye(8), rtol=0, atol=1e-7)            # checkFitTol of the driver
