@@ -702,17 +702,45 @@ extern "C" int hipeig_gram(hipeig_ctx* c, int64_t n, int ma, const double* const
 }
 
 // ---- Gram-Schmidt ------------------------------------------------------------------------
-// reference MGS step (numpyVector.py:134-138): t1 = x.q and t2 = q.q in one sweep
+// The reference's sequential MGS (numpyVector.py:132-139: per q  t1 = x.q, t2 = q.q, x = x - q*(t1/t2)) as ONE kernel per
+// basis vector plus one: kernel j applies the update of q_{j-1} with the totals kernel j-1 left and, on the updated x in
+// the same pass, forms the two dots with q_j; the kernel behind the last vector applies the last update and forms x.x,
+// the inner product the lindep test needs (:140).  Round 3 ran dots, a 2-workgroup sum and the update as three launches
+// per vector and read x twice: 40N bytes per vector against 32N now.  Same element-wise roundings as the reference:
+// x + (-(q * coef)), two roundings.
 __global__ void __launch_bounds__(HIPEIG_BLOCK)
-mgs_dots_kernel(int64_t n, const double* __restrict__ x, const double* __restrict__ q,
-                double* __restrict__ partials, double* __restrict__ group_partials, unsigned* counters, double* __restrict__ out) {
+mgs_sweep_kernel(int64_t n, double* __restrict__ x, const double* __restrict__ q_prev, const double* __restrict__ t_prev,
+                 const double* __restrict__ q_next, double* __restrict__ partials, double* __restrict__ group_partials,
+                 unsigned* counters, double* __restrict__ out) {
   __shared__ double lds[HIPEIG_BLOCK];
+  const double coef = q_prev ? t_prev[0] / t_prev[1] : 0.0;
+  const int64_t n2 = n >> 1;
+  double2* x2 = reinterpret_cast<double2*>(x);
+  const double2* p2 = reinterpret_cast<const double2*>(q_prev);
+  const double2* q2 = reinterpret_cast<const double2*>(q_next);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   double a = 0.0, b = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const double qv = q[i];
-    a = fma(x[i], qv, a);
-    b = fma(qv, qv, b);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    double2 xv = x2[i];
+    if (q_prev) {
+      const double2 pv = p2[i];
+      xv.x = add_rn(xv.x, -mul_rn(pv.x, coef));
+      xv.y = add_rn(xv.y, -mul_rn(pv.y, coef));
+      x2[i] = xv;
+    }
+    if (q_next) {
+      const double2 qv = q2[i];
+      a = fma(xv.x, qv.x, a); a = fma(xv.y, qv.y, a);
+      b = fma(qv.x, qv.x, b); b = fma(qv.y, qv.y, b);
+    } else {
+      a = fma(xv.x, xv.x, a); a = fma(xv.y, xv.y, a);
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    double xv = x[n - 1];
+    if (q_prev) { xv = add_rn(xv, -mul_rn(q_prev[n - 1], coef)); x[n - 1] = xv; }
+    if (q_next) { a = fma(xv, q_next[n - 1], a); b = fma(q_next[n - 1], q_next[n - 1], b); }
+    else a = fma(xv, xv, a);
   }
   a = block_reduce_sum(a, lds);
   b = block_reduce_sum(b, lds);
@@ -721,18 +749,6 @@ mgs_dots_kernel(int64_t n, const double* __restrict__ x, const double* __restric
     agent_store_nowait(partials + 2 * blockIdx.x + 1, b);
   }
   finish_records(partials, group_partials, 2, counters, lds, out);
-}
-
-// x <- 1.0*x + (-1.0)*(q*(t1/t2)): the reference's roundings, element by element
-__global__ void __launch_bounds__(HIPEIG_BLOCK)
-mgs_update_kernel(int64_t n, const double* __restrict__ t, const double* __restrict__ q,
-                  double* __restrict__ x) {
-  const double coef = t[0] / t[1];
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const double proj = mul_rn(q[i], coef);
-    x[i] = add_rn(x[i], -proj);
-  }
 }
 
 // ---- sequential MGS projection with the coefficients kept on the device -------------------
@@ -1632,15 +1648,21 @@ extern "C" int hipeig_orthonormalize(hipeig_ctx* c, int64_t n, int m, const doub
                                      int* is_lindep) {
   HIPEIG_REQUIRE(innerprod && is_lindep, "null outputs");
   HIPEIG_REQUIRE(method == 0 || method == 1, "method must be 0 (MGS) or 1 (CGS2)");
+  double ip = 0.0;
   if (method == 0) {
+    // kernel j: update with q_{j-1}, dots with q_j; totals alternate between two slots of the scalar area (kernel j reads
+    // slot j-1 while its last workgroup writes slot j); the last kernel's x.x goes to the host
     const int g = grid_for(n, 4);
-    for (int j = 0; j < m; ++j) {
-      hipLaunchKernelGGL(mgs_dots_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, x, Y[j], c->d_partials,
-                         c->d_group_partials, c->d_counters + 3 * HIPEIG_TICKET_WORDS, c->d_scalars);
-      if (records_to_host(c, 2, nullptr)) return 4;
-      hipLaunchKernelGGL(mgs_update_kernel, dim3(grid_stream(n)), dim3(HIPEIG_BLOCK), 0, c->stream, n, c->d_scalars, Y[j], x);
+    unsigned* cnt = c->d_counters + 3 * HIPEIG_TICKET_WORDS;
+    for (int j = 0; j <= m; ++j) {
+      double* slot = (j == m) ? record_target(c, true) : c->d_scalars + 8 + 2 * (j & 1);
+      const double* prev = c->d_scalars + 8 + 2 * ((j + 1) & 1);
+      hipLaunchKernelGGL(mgs_sweep_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, x, j > 0 ? Y[j - 1] : nullptr, prev,
+                         j < m ? Y[j] : nullptr, c->d_partials, c->d_group_partials, cnt, slot);
       HIPEIG_CHECK(hipGetLastError());
+      if (j < m && c->collectives && hipeig_allreduce_sum(c, slot, 2)) return 4;
     }
+    if (records_to_host(c, 1, &ip)) return 4;
   } else {
     const int cap = HIPEIG_MAX_COLS * HIPEIG_MAX_COLS;
     for (int pass = 0; pass < 2; ++pass) {
@@ -1651,9 +1673,10 @@ extern "C" int hipeig_orthonormalize(hipeig_ctx* c, int64_t n, int m, const doub
       }
     }
   }
-  double ip = 0.0;
-  int rc = hipeig_dot(c, n, x, x, &ip);
-  if (rc) return rc;
+  if (method != 0) {
+    int rc = hipeig_dot(c, n, x, x, &ip);
+    if (rc) return rc;
+  }
   *innerprod = ip;
   if (ip > lindep) {
     *is_lindep = 0;

@@ -65,8 +65,9 @@ def main():
     for m in (8, 16, 32):
         for method in ("cgs2", "mgs"):
             passes = 2 if method == "cgs2" else 1
-            # cgs2: 2 x (multi_dot + multi_axpy) = 2 x ((m+1) + (m+2)) vector passes; mgs: m x (dot 2 + update 3)
-            nbytes = (2 * ((m + 1) + (m + 2)) if method == "cgs2" else 5 * m) * B
+            # cgs2: 2 x (multi_dot + multi_axpy) = 2 x ((m+1) + (m+2)) vector passes; mgs (round 4, one fused kernel per
+            # vector): first kernel x + q (2), middle kernels x, q_prev, q_next + x written (4 each), last x, q_prev + x (3)
+            nbytes = (2 * ((m + 1) + (m + 2)) if method == "cgs2" else 2 + 4 * (m - 1) + 3) * B
             x = ea.HipVector(host.copy(), {"orthogonalization": method})
             timed(f"orthogonalize_against_set m={m} {method}", nbytes,
                   lambda r, m=m, x=x: V.orthogonalize_against_set(x, pick(r, m)), reps=6)
