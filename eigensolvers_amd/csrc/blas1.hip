@@ -29,8 +29,7 @@ struct CoefTable {
 // Two levels because one workgroup adding 2048 records of 1 KiB would take longer than the launch it replaces; the group
 // sums run on as many CUs as there are groups.  Order and tree are fixed by (gridDim.x, nv): bitwise reproducible.
 #define REC_GROUP 64
-#define REC_MAX_GROUPS 32
-#define REC_MAX_VALUES 1024
+#define REC_GROUP_DOUBLES 32768            // size of ctx->d_group_partials: (groups) x (values per record) must fit
 
 __device__ __forceinline__ double agent_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void agent_store_nowait(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1652,7 +1651,16 @@ extern "C" int hipeig_orthonormalize(hipeig_ctx* c, int64_t n, int m, const doub
   if (method == 0) {
     // kernel j: update with q_{j-1}, dots with q_j; totals alternate between two slots of the scalar area (kernel j reads
     // slot j-1 while its last workgroup writes slot j); the last kernel's x.x goes to the host
-    const int g = grid_for(n, 4);
+    // Grid: every workgroup pays a fixed price for its record (store, wait, ticket), so FEWER, fatter workgroups win as long
+    // as the chip stays busy - measured (tools/experiments/mgs_grid.sh, m = 16): N = 1e7 2 / 8 / 32 / 64 / 128 elements per
+    // thread -> 1.71 / 1.16 / 0.93 / 0.97 / 1.44 ms; N = 1e6 2 / 8 / 16 / 32 -> 0.42 / 0.277 / 0.275 / 0.35 ms.  Hence
+    // n / 8192 workgroups, but at least two per CU (as far as n / 1024 goes).
+    int64_t g64 = n / 8192, floor2 = n / 1024 < 2 * (int64_t)c->num_cu ? n / 1024 : 2 * (int64_t)c->num_cu;
+    if (g64 < floor2) g64 = floor2;
+    if (const char* e = getenv("HIPEIG_MGS_PER_THREAD")) g64 = atoi(e) > 0 ? n / (256 * (int64_t)atoi(e)) : g64;      // tuning knob
+    if (g64 < 1) g64 = 1;
+    if (g64 > HIPEIG_WIDE_PARTIALS / 2) g64 = HIPEIG_WIDE_PARTIALS / 2;        // groups x 2 values fit the group-record area
+    const int g = (int)g64;
     unsigned* cnt = c->d_counters + 3 * HIPEIG_TICKET_WORDS;
     for (int j = 0; j <= m; ++j) {
       double* slot = (j == m) ? record_target(c, true) : c->d_scalars + 8 + 2 * (j & 1);
