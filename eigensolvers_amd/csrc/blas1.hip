@@ -132,6 +132,22 @@ static int records_to_host(hipeig_ctx* c, int ncols, double* host_out) {
   return 0;
 }
 
+// Grid of a streaming kernel that ends in finish_records: every workgroup pays a fixed price for its record (store, wait,
+// ticket), so FEWER, fatter workgroups win as long as the chip stays busy.  Measured (tools/experiments/mgs_grid.sh,
+// multidot_grid.sh; profiles/r04_mgs_fused_sweep_grid.txt, r04_multidot_grid.txt): MGS m = 16 at N = 1e7 with 2 / 8 / 32 /
+// 64 / 128 elements per thread 1.71 / 1.16 / 0.93 / 0.97 / 1.44 ms, at N = 1e6 with 2 / 8 / 16 / 32: 0.42 / 0.277 / 0.275 /
+// 0.35 ms; multi_dot m = 16 at N = 1e7 with 2 / 32 / 48: 0.273 / 0.245 / 0.267 ms, at N = 1e6 with 2 / 4 / 8 / 16: 0.063 /
+// 0.053 / 0.054 / 0.072 ms.  Hence n / 8192 workgroups, but at least two per CU (as far as n / 1024 goes).
+static int grid_records(const hipeig_ctx* c, int64_t n, const char* knob) {
+  int64_t g = n / 8192;
+  const int64_t floor2 = n / 1024 < 2 * (int64_t)c->num_cu ? n / 1024 : 2 * (int64_t)c->num_cu;
+  if (g < floor2) g = floor2;
+  if (const char* e = knob ? getenv(knob) : nullptr) g = atoi(e) > 0 ? n / (256 * (int64_t)atoi(e)) : g;      // tuning knob: elements per thread
+  if (g < 1) g = 1;
+  if (g > HIPEIG_MAX_PARTIALS) g = HIPEIG_MAX_PARTIALS;
+  return (int)g;
+}
+
 // ---- dot / nrm2 ------------------------------------------------------------------------
 // The total is formed by the kernel's last workgroup (common.h) and stored to `out` - on one GPU the pinned, mapped host
 // word, so that a dot product is ONE launch and a stream wait (round 2: two launches).
@@ -489,7 +505,7 @@ static int multi_dot_launch(hipeig_ctx* c, int64_t n, int m, const double* const
 static int multi_dot_impl(hipeig_ctx* c, int64_t n, int m, const double* const* Y, const double* x,
                           double* host_out) {
   HIPEIG_REQUIRE(m >= 1 && m <= HIPEIG_MAX_COLS * HIPEIG_MAX_COLS, "too many columns for one call");
-  const int g = grid_for(n, 2);
+  const int g = grid_records(c, n, "HIPEIG_MULTIDOT_PER_THREAD");
   double* target = record_target(c, host_out != nullptr);
   for (int j0 = 0; j0 < m; j0 += HIPEIG_MAX_COLS) {
     const int mm = (m - j0 < HIPEIG_MAX_COLS) ? (m - j0) : HIPEIG_MAX_COLS;
@@ -1651,16 +1667,7 @@ extern "C" int hipeig_orthonormalize(hipeig_ctx* c, int64_t n, int m, const doub
   if (method == 0) {
     // kernel j: update with q_{j-1}, dots with q_j; totals alternate between two slots of the scalar area (kernel j reads
     // slot j-1 while its last workgroup writes slot j); the last kernel's x.x goes to the host
-    // Grid: every workgroup pays a fixed price for its record (store, wait, ticket), so FEWER, fatter workgroups win as long
-    // as the chip stays busy - measured (tools/experiments/mgs_grid.sh, m = 16): N = 1e7 2 / 8 / 32 / 64 / 128 elements per
-    // thread -> 1.71 / 1.16 / 0.93 / 0.97 / 1.44 ms; N = 1e6 2 / 8 / 16 / 32 -> 0.42 / 0.277 / 0.275 / 0.35 ms.  Hence
-    // n / 8192 workgroups, but at least two per CU (as far as n / 1024 goes).
-    int64_t g64 = n / 8192, floor2 = n / 1024 < 2 * (int64_t)c->num_cu ? n / 1024 : 2 * (int64_t)c->num_cu;
-    if (g64 < floor2) g64 = floor2;
-    if (const char* e = getenv("HIPEIG_MGS_PER_THREAD")) g64 = atoi(e) > 0 ? n / (256 * (int64_t)atoi(e)) : g64;      // tuning knob
-    if (g64 < 1) g64 = 1;
-    if (g64 > HIPEIG_WIDE_PARTIALS / 2) g64 = HIPEIG_WIDE_PARTIALS / 2;        // groups x 2 values fit the group-record area
-    const int g = (int)g64;
+    const int g = grid_records(c, n, "HIPEIG_MGS_PER_THREAD");
     unsigned* cnt = c->d_counters + 3 * HIPEIG_TICKET_WORDS;
     for (int j = 0; j <= m; ++j) {
       double* slot = (j == m) ? record_target(c, true) : c->d_scalars + 8 + 2 * (j & 1);
