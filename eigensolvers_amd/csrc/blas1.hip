@@ -184,7 +184,7 @@ dot_kernel(int64_t n, const double* __restrict__ x, const double* __restrict__ y
 
 extern "C" int hipeig_dot(hipeig_ctx* c, int64_t n, const double* x, const double* y, double* out) {
   HIPEIG_REQUIRE(out != nullptr, "null output");
-  const int g = grid_for(n, 8);
+  const int g = grid_records(c, n, "HIPEIG_DOT_PER_THREAD");
   unsigned* cnt = c->d_counters + 3 * HIPEIG_TICKET_WORDS;
   const bool direct = !c->collectives && c->h_scalars_dev;
   hipLaunchKernelGGL(dot_kernel, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, x, y, c->d_partials, cnt,

@@ -163,14 +163,14 @@ struct hipeig_csr {
   int32_t last_pair_fused;   // 1 when the most recent pair product ran as one sweep
   int reproducible;          // automatic choice restricted to bitwise reproducible kernels (hipeig_csr_set_reproducible)
   double absrow_max;         // max_i sum_j |a_ij| over the local rows: overflow bound of the fixed-point sweep (variant 5)
-  // block-operand copies ("TCOO-B", spmm_device.h): one per interleave width, [0]: K = 4, [1]: K = 8; built on first use
+  // block-operand copies ("TCOO-B", spmm_device.h): one per interleave width, [0]: K = 4, [1]: K = 8, [2]: K = 16; built on first use
   struct BcooLayout {
     uint32_t* idx;
     double* val;
     uint32_t* off;
     int32_t nunits, nwin, wbits, rw, wgs_per_sweep;
     int32_t state;           // 0 = undecided, 1 = built, 2 = not suited (row-owner kernel is used)
-  } bl[2];
+  } bl[3];
   int32_t block_variant;     // 0 = automatic, 1 = row-owner CSR, 2 = TCOO-B
   int32_t last_block_variant, last_block_k;
   int64_t gather_len;        // length of the gathered operand (ncols, or gl.total())

@@ -15,7 +15,7 @@
 #include "minres_device.h"
 #include "spmm_device.h"
 
-int hipeig_block_pick_variant(hipeig_ctx* c, hipeig_csr* A, int K);
+int hipeig_block_pick_variant(hipeig_ctx* c, hipeig_csr* A, int K, int for_solve);
 BcooView hipeig_bcoo_view(const hipeig_csr* A, int K);
 size_t hipeig_bcoo_lds_bytes(const hipeig_csr* A, int K);
 int hipeig_bcoo_grid(const hipeig_csr* A, int K);
@@ -288,7 +288,7 @@ static int minres_block_impl(hipeig_ctx* c, hipeig_csr* A, double sigma, double 
   HIPEIG_CHECK(hipMemcpyAsync(V, h, K * sizeof(MinresState), hipMemcpyHostToDevice, c->stream));
   if (hipeig_sync_checked(c)) return 4;       // the pinned records are rewritten by the first copy-back
 
-  const int bv = hipeig_block_pick_variant(c, A, K);
+  const int bv = hipeig_block_pick_variant(c, A, K, 1);
   if (bv < 0) return 1;
   const BcooView tview = hipeig_bcoo_view(A, K);
   if (bv == 2)

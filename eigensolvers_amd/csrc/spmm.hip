@@ -4,10 +4,10 @@
 #include <vector>
 #include "spmm_device.h"
 
-struct PtrTable8 { const double* p[BCOO_KMAX]; };
-struct OutTable8 { double* p[BCOO_KMAX]; };
+struct PtrTable8 { const double* p[BCOO_KPACK]; };
+struct OutTable8 { double* p[BCOO_KPACK]; };
 
-static inline int layout_slot(int K) { return K == 4 ? 0 : 1; }
+static inline int layout_slot(int K) { return K == 4 ? 0 : K == 8 ? 1 : 2; }
 
 // ---- interleave / de-interleave ---------------------------------------------------------
 // Thread t owns the 16-byte pair (2t, 2t+1) of the block: row t / (K/2), operands 2(t % (K/2)) and the next,
@@ -16,13 +16,13 @@ static inline int layout_slot(int K) { return K == 4 ? 0 : 1; }
 __device__ __forceinline__ const double* pick8(const PtrTable8& t, int j) {
   const double* p = t.p[0];
 #pragma unroll
-  for (int q = 1; q < BCOO_KMAX; ++q) p = (j == q) ? t.p[q] : p;
+  for (int q = 1; q < BCOO_KPACK; ++q) p = (j == q) ? t.p[q] : p;
   return p;
 }
 __device__ __forceinline__ double* pick8(const OutTable8& t, int j) {
   double* p = t.p[0];
 #pragma unroll
-  for (int q = 1; q < BCOO_KMAX; ++q) p = (j == q) ? t.p[q] : p;
+  for (int q = 1; q < BCOO_KPACK; ++q) p = (j == q) ? t.p[q] : p;
   return p;
 }
 
@@ -60,25 +60,27 @@ block_unpack_kernel(int64_t n, int k, const double* __restrict__ blk, OutTable8 
 }
 
 int hipeig_block_pack(hipeig_ctx* c, int K, int64_t n, int k, const double* const* cols, double* blk) {
-  HIPEIG_REQUIRE((K == 4 || K == 8) && k >= 1 && k <= K, "a block holds 1..K operands, K = 4 or 8");
+  HIPEIG_REQUIRE((K == 4 || K == 8 || K == 16) && k >= 1 && k <= K, "a block holds 1..K operands, K = 4, 8 or 16");
   if (n == 0) return 0;
   PtrTable8 t;
-  for (int j = 0; j < BCOO_KMAX; ++j) t.p[j] = j < k ? cols[j] : nullptr;
+  for (int j = 0; j < BCOO_KPACK; ++j) t.p[j] = j < k ? cols[j] : nullptr;
   const int g = grid_stream(n * (K / 2) * 2);
   if (K == 4) hipLaunchKernelGGL(block_pack_kernel<4>, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, k, t, blk);
-  else hipLaunchKernelGGL(block_pack_kernel<8>, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, k, t, blk);
+  else if (K == 8) hipLaunchKernelGGL(block_pack_kernel<8>, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, k, t, blk);
+  else hipLaunchKernelGGL(block_pack_kernel<16>, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, k, t, blk);
   HIPEIG_CHECK(hipGetLastError());
   return 0;
 }
 
 int hipeig_block_unpack(hipeig_ctx* c, int K, int64_t n, int k, const double* blk, double* const* cols) {
-  HIPEIG_REQUIRE((K == 4 || K == 8) && k >= 1 && k <= K, "a block holds 1..K operands, K = 4 or 8");
+  HIPEIG_REQUIRE((K == 4 || K == 8 || K == 16) && k >= 1 && k <= K, "a block holds 1..K operands, K = 4, 8 or 16");
   if (n == 0) return 0;
   OutTable8 t;
-  for (int j = 0; j < BCOO_KMAX; ++j) t.p[j] = j < k ? cols[j] : nullptr;
+  for (int j = 0; j < BCOO_KPACK; ++j) t.p[j] = j < k ? cols[j] : nullptr;
   const int g = grid_stream(n * (K / 2) * 2);
   if (K == 4) hipLaunchKernelGGL(block_unpack_kernel<4>, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, k, blk, t);
-  else hipLaunchKernelGGL(block_unpack_kernel<8>, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, k, blk, t);
+  else if (K == 8) hipLaunchKernelGGL(block_unpack_kernel<8>, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, k, blk, t);
+  else hipLaunchKernelGGL(block_unpack_kernel<16>, dim3(g), dim3(HIPEIG_BLOCK), 0, c->stream, n, k, blk, t);
   HIPEIG_CHECK(hipGetLastError());
   return 0;
 }
@@ -132,17 +134,23 @@ int hipeig_bcoo_grid(const hipeig_csr* A, int K) {
 }
 
 // Decide between the window-blocked and the row-owner block kernel for interleave width K and build the
-// former's layout (idempotent).  Returns 2 (TCOO-B) or 1 (row-owner), -1 on failure.
-int hipeig_block_pick_variant(hipeig_ctx* c, hipeig_csr* A, int K) {
+// former's layout (idempotent).  Returns 2 (TCOO-B) or 1 (row-owner), -1 on failure.  for_solve: the caller is the block
+// MINRES, whose sweeps leave per-workgroup partials - it cannot take a layout that needs more than HIPEIG_MAX_PARTIALS
+// workgroups per product and keeps the row-owner kernel there (N = 1e7: 16 sweeps of 256).
+int hipeig_block_pick_variant(hipeig_ctx* c, hipeig_csr* A, int K, int for_solve) {
   auto& L = A->bl[layout_slot(K)];
   A->last_block_k = K;
   if (A->block_variant == 1 || A->nnz == 0 || A->nrows == 0) return A->last_block_variant = 1;
   // an operator pinned to a reproducible kernel (variants 1-3, 5) keeps that promise for block products and block
   // solves too: the row-owner kernel adds a row's terms in a fixed order, the window-blocked one uses fp64 atomics
   if (A->block_variant == 0 && (A->reproducible || (A->variant != 0 && A->variant != 4))) return A->last_block_variant = 1;
-  if (L.state == 1) return A->last_block_variant = 2;
+  auto fits_solve = [&](const hipeig_csr::BcooLayout& l) {
+    const int64_t g = l.wgs_per_sweep < l.nunits ? l.wgs_per_sweep : l.nunits;
+    return g > 0 && ((l.nunits + g - 1) / g) * g <= HIPEIG_MAX_PARTIALS;
+  };
+  if (L.state == 1) return A->last_block_variant = (for_solve && A->block_variant == 0 && !fits_solve(L)) ? 1 : 2;
   if (L.state == 2 && A->block_variant == 0) return A->last_block_variant = 1;
-  int wbits = K == 8 ? 11 : 12;                          // 128 KiB of the operand block per window (measured best of 2^8..2^15 rows at N = 1e6,
+  int wbits = K == 16 ? 10 : K == 8 ? 11 : 12;           // 128 KiB of the operand block per window (measured best of 2^8..2^15 rows at N = 1e6,
                                                          // K = 8: 32 windows fit one L2, so workgroups that drift apart still hit)
   if (const char* e = getenv("HIPEIG_BCOO_WBITS")) wbits = atoi(e);          // tuning knob
   if (wbits < 8 || wbits > 20) { hipeig_set_error("HIPEIG_BCOO_WBITS out of range"); return -1; }
@@ -157,14 +165,23 @@ int hipeig_block_pick_variant(hipeig_ctx* c, hipeig_csr* A, int K) {
   if (rw < 8) rw = 8;
   if (rw > rw_max) rw = rw_max;
   if (const char* e = getenv("HIPEIG_BCOO_RW")) { rw = atoi(e); if (rw < 1 || rw > rw_max) { hipeig_set_error("HIPEIG_BCOO_RW out of range"); return -1; } }
-  // L2 reuse of the operand lines inside one XCD (32 workgroups share a window): below ~2 touches per
-  // line the windows buy nothing (spmm_device.h); a block that fits one L2 needs no windows either.
+  // L2 reuse of the operand lines inside one XCD (32 workgroups share a window): round 2 kept the windows only above ~2
+  // touches per line (spmm_device.h).  Round 4 measured the other end (tools/experiments/pair_block_width.py, block_bench.py):
+  // once the operand block has outgrown the 256 MiB Infinity Cache the row-owner kernel's gathers go to HBM one line each
+  // and the windows win although hardly a line is touched twice - N = 1e7: K = 8 15.2 -> 11.8 ms per product, 8 complex
+  // operands (K = 16) 2.90 -> 1.85 ms per operand - and the 16-wide block wins with them at N = 1e6 too (0.134 -> 0.109).
+  // A block that fits one L2 needs no windows.
   const double rows_per_line = 128.0 / (K * 8);
   const double touches = 32.0 * (double)rw * ((double)A->nnz / (double)A->nrows) * rows_per_line / (double)A->gather_len;
   const bool fits_l2 = A->gather_len * (int64_t)(K * 8) <= ((int64_t)3 << 20);
-  if (A->block_variant == 0 && (touches < 2.0 || fits_l2)) {
+  const bool beyond_mall = A->gather_len * (int64_t)(K * 8) > ((int64_t)256 << 20);
+  if (A->block_variant == 0 && (fits_l2 || (touches < 2.0 && !beyond_mall && K != 16))) {
     L.state = 2;
     return A->last_block_variant = 1;
+  }
+  if (for_solve && A->block_variant == 0) {            // would the layout fit the solve?  (same arithmetic as below)
+    const int64_t nu = (A->nrows + rw - 1) / rw, g = nu < c->num_cu ? nu : c->num_cu;
+    if (((nu + g - 1) / g) * g > HIPEIG_MAX_PARTIALS) return A->last_block_variant = 1;      // state stays undecided: a product may still build it
   }
   const int64_t nunits = (A->nrows + rw - 1) / rw;
   const size_t ntile = (size_t)nunits * (size_t)nwin;
@@ -268,7 +285,7 @@ int hipeig_rowowner_grid(const hipeig_ctx* c, const hipeig_csr* A) {
 template <int K, class Epi>
 static int spmm_block_run(hipeig_ctx* c, hipeig_csr* A, const double* Xb, const Epi& epi) {
   if (A->nrows == 0) return 0;
-  const int bv = hipeig_block_pick_variant(c, A, K);
+  const int bv = hipeig_block_pick_variant(c, A, K, 0);
   if (bv < 0) return 1;
   const double* xg = nullptr;
   if (hipeig_block_allgather(c, A, K, Xb, &xg)) return 4;
@@ -346,15 +363,22 @@ extern "C" int hipeig_spmm_shift_pairs(hipeig_ctx* c, hipeig_csr* A, int npairs,
     return 0;
   }
   const int64_t nx = A->ncols, ny = A->nrows;
-  if (ensure_blk_ws(c, (size_t)(nx + ny) * BCOO_KMAX)) return 1;
+  // complex operands per pass over the operator: 4 (an 8-wide block, 64 B per operand row: a gather uses half a line) or 8
+  // (16 wide, 128 B = one whole line per gather; HIPEIG_PAIR_BLOCK_WIDTH, see EXPERIMENTS.md R4-block16)
+  // Measured per complex operand: N = 1e6 0.107 (4 per pass) / 0.109 (8); N = 1e7 2.98 / 1.85 ms (single pair products:
+  // 0.177 / 3.94) - 8 per pass once the 16-wide operand block (128 B per row) no longer sits in the caches.
+  int wide = (nx * (int64_t)128 > ((int64_t)192 << 20)) ? 8 : 4;
+  if (const char* e = getenv("HIPEIG_PAIR_BLOCK_WIDTH")) wide = atoi(e) >= 8 ? 8 : 4;
+  if (ensure_blk_ws(c, (size_t)(nx + ny) * BCOO_KPACK)) return 1;
   double* Xi = c->blk_ws;
-  double* Yi = c->blk_ws + (size_t)nx * BCOO_KMAX;
+  double* Yi = c->blk_ws + (size_t)nx * BCOO_KPACK;
   const double ar = sign * zr, ai = sign * zi, as = -sign;
   for (int p0 = 0; p0 < npairs;) {
-    const int np = (npairs - p0 >= 4) ? 4 : ((npairs - p0 > 2) ? npairs - p0 : (npairs - p0));
-    const int K = (np <= 2) ? 4 : 8;
-    const double* cols[BCOO_KMAX];
-    double* outs[BCOO_KMAX];
+    const int left = npairs - p0;
+    const int np = (wide == 8 && left > 4) ? (left < 8 ? left : 8) : (left < 4 ? left : 4);
+    const int K = (np <= 2) ? 4 : (np <= 4) ? 8 : 16;
+    const double* cols[BCOO_KPACK];
+    double* outs[BCOO_KPACK];
     for (int p = 0; p < np; ++p) {
       cols[2 * p] = Xre[p0 + p]; cols[2 * p + 1] = Xim[p0 + p];
       outs[2 * p] = Yre[p0 + p]; outs[2 * p + 1] = Yim[p0 + p];
@@ -362,7 +386,8 @@ extern "C" int hipeig_spmm_shift_pairs(hipeig_ctx* c, hipeig_csr* A, int npairs,
     if (hipeig_block_pack(c, K, nx, 2 * np, cols, Xi)) return 1;
     int rc;
     if (K == 4) rc = spmm_block_run<4>(c, A, Xi, ShiftPairBlockEpilogue<4>{ar, ai, as, Xi + A->row_offset * 4, Yi});
-    else rc = spmm_block_run<8>(c, A, Xi, ShiftPairBlockEpilogue<8>{ar, ai, as, Xi + A->row_offset * 8, Yi});
+    else if (K == 8) rc = spmm_block_run<8>(c, A, Xi, ShiftPairBlockEpilogue<8>{ar, ai, as, Xi + A->row_offset * 8, Yi});
+    else rc = spmm_block_run<16>(c, A, Xi, ShiftPairBlockEpilogue<16>{ar, ai, as, Xi + A->row_offset * 16, Yi});
     if (rc) return rc;
     if (hipeig_block_unpack(c, K, ny, 2 * np, Yi, outs)) return 1;
     p0 += np;
@@ -371,7 +396,7 @@ extern "C" int hipeig_spmm_shift_pairs(hipeig_ctx* c, hipeig_csr* A, int npairs,
 }
 
 extern "C" int hipeig_csr_block_info(hipeig_csr* A, int64_t info[4]) {
-  const auto& L = A->bl[layout_slot(A->last_block_k == 4 ? 4 : 8)];
+  const auto& L = A->bl[layout_slot(A->last_block_k == 4 ? 4 : A->last_block_k == 16 ? 16 : 8)];
   info[0] = A->last_block_variant; info[1] = L.nunits; info[2] = L.nwin; info[3] = L.rw;
   return 0;
 }

@@ -28,18 +28,19 @@
 #pragma once
 #include "common.h"
 
-#define BCOO_KMAX 8                       // widest interleave (operands per block, zero padded); K = 4 for blocks of <= 4
+#define BCOO_KMAX 8                       // widest interleave of the block SOLVES (operands per block, zero padded); K = 4 for blocks of <= 4
+#define BCOO_KPACK 16                     // widest interleave of a block PRODUCT: 8 complex operands of a contour point (128 B = one line per operand row)
 #define BCOO_THREADS 1024
 #define BCOO_GATHERS 8                    // gather instructions a wave keeps in flight (measured: 4 / 8 / 16 -> 0.41 / 0.385 / 0.53 ms)
 #define BCOO_MAX_WIN 4096                 // (nwin + 2) offsets share the dynamic LDS with the accumulators
 #define HIPEIG_BCOO_LDS_MAX ((size_t)161792)     // dynamic LDS; 2 KiB of the CU's 160 KiB stay for the kernels' static arrays
 
 template <int K> struct BcooShape {
-  static_assert(K == 4 || K == 8, "interleave width is 4 or 8");
+  static_assert(K == 4 || K == 8 || K == 16, "interleave width is 4, 8 or 16");
   static constexpr int LPN = K / 2;               // lanes per non-zero: each lane owns 16 B (two operands) of the operand row
   static constexpr int NPI = 64 / LPN;            // non-zeros per gather instruction
   static constexpr int ROUNDS = 64 / NPI;         // gather instructions per 64 non-zeros
-  static constexpr int NB = BCOO_GATHERS / ROUNDS; // sub-batches of 64 non-zeros per wave step
+  static constexpr int NB = BCOO_GATHERS / ROUNDS > 0 ? BCOO_GATHERS / ROUNDS : 1; // sub-batches of 64 non-zeros per wave step
   static constexpr int MAX_RW = (int)(HIPEIG_BCOO_LDS_MAX / (K * 8)) - 8;     // accumulator rows per workgroup
 };
 

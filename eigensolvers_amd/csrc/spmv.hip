@@ -971,7 +971,7 @@ extern "C" int hipeig_csr_destroy(hipeig_ctx* c, hipeig_csr* A) {
   if (A->p_idx) hipFree(A->p_idx);
   if (A->p_val) hipFree(A->p_val);
   if (A->p_off) hipFree(A->p_off);
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < 3; ++q) {
     if (A->bl[q].idx) hipFree(A->bl[q].idx);
     if (A->bl[q].val) hipFree(A->bl[q].val);
     if (A->bl[q].off) hipFree(A->bl[q].off);

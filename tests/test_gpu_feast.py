@@ -362,6 +362,54 @@ def test_block_complex_shift_product_matches_the_single_products(hip, N):
         assert H.block_info()["variant"] == "column-window-blocked"
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+def test_eight_complex_operands_per_pass(hip, monkeypatch, variant):
+    """Round 4: 8 complex operands of a contour point share one pass over the operator as a 16-wide block (128 bytes = one
+    line per operand row; what config #5 runs at N = 1e7).  Forced here at a small size through its knob, in both block
+    kernels (1 row-owner, 2 column-window blocked), for 5..11 operands (a 16-wide pass + remainders of every width), both
+    signs, against the single pair products."""
+    N = 70_001                                     # odd: the last operand row sits alone in its pair
+    H = hip.HipCsrOperator.generate(N, 32, seed=7)
+    H.set_block_variant(variant)
+    monkeypatch.setenv("HIPEIG_PAIR_BLOCK_WIDTH", "8")
+    rng = np.random.default_rng(variant)
+    ctx = hip.HipContext.default()
+    z = -0.07 + 0.19j
+    for npairs, reverse in ((5, False), (7, True), (8, False), (11, False)):
+        xs = [(hip.HipVector(rng.standard_normal(N)), hip.HipVector(rng.standard_normal(N))) for _ in range(npairs)]
+        ys = H.apply_shifted_pairs(z, [(a._buf, b._buf) for a, b in xs], reverse=reverse)
+        for (xr, xi), (yr, yi) in zip(xs, ys):
+            rr, ri = ctx.alloc(N), ctx.alloc(N)
+            H.apply_shifted_pair(z, xr._buf, xi._buf, rr, ri, reverse=reverse)
+            ref = hip.HipVector(rr).array + 1j * hip.HipVector(ri).array
+            got = hip.HipVector(yr).array + 1j * hip.HipVector(yi).array
+            assert np.max(np.abs(got - ref)) <= 1e-14 * np.max(np.abs(ref))
+    assert H.block_info()["variant"] == ("row-owner" if variant == 1 else "column-window-blocked")
+
+
+def test_feast_at_the_reference_comparable_inner_tolerance(hip):
+    """Config #5's recipe at N = 2e4 with gcrotmk rtol 1e-5 - the inner tolerance N = 1e7 needs (EXPERIMENTS.md R3-feast:
+    looser ones do not converge there), run to the reference's stopping rule (feast.py:226-231)."""
+    import warnings
+    import scipy.linalg as la
+    from eigensolvers_amd.generators import gapped_params
+    N, m0 = 20_000, 16
+    H = hip.HipCsrOperator.generate(N, 32, seed=7)
+    Q = la.qr(np.random.default_rng(9).standard_normal((N, m0)), mode="economic")[0]
+    o = {"linearSystemArgs": {"linearSolver": "gcrotmk", "linearIter": 4000, "linear_tol": 1e-5, "linear_atol": 1e-7,
+                              "arnoldiColumnsPerPass": 4}}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ev, Y, st = hip.feastDiagonalization(H, [hip.HipVector(Q[:, i].copy(), o) for i in range(m0)], 16, "legendre",
+                                             -0.21, 0.21, 1e-4, 12, writeOut=False)
+    assert st["residual"] < 1e-4 and 2 <= st["outerIter"] <= 10
+    inside = np.sort(ev[(ev > -0.21) & (ev < 0.21)])
+    targets = np.sort(gapped_params(N, 32, 7)["targets"])
+    assert len(inside) == 16 and np.all(np.abs(inside - targets) < 2e-3)
+    res = hip.true_residual_norms(H, ev, Y, m0)
+    assert np.all(res < 1e-2), res
+
+
 @pytest.mark.parametrize("cols", [1, 4])
 def test_contour_solves_in_lock_step_equal_the_single_solves(hip, cols):
     """HipVector.solveBlock with a complex shift and gcrotmk: the right-hand sides of one contour point advance in lock
