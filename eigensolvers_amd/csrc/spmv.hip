@@ -701,6 +701,9 @@ static int build_tcoow_layout(hipeig_ctx* c, hipeig_csr* A, int pair) {
     // Worth it only when x is much larger than the L2s (measured: slab of N = 1e7 on 1/8 of the rows
     // 0.53 -> 0.34 ms, on 1/4 0.90 -> 0.62 ms; at N = 1e6, x = 8 MB, the combine launch costs more than
     // the sweep gains: MINRES iteration 0.141 -> 0.163 ms).
+    // Half of what the splits buy on these slabs is column locality per XCD (round 4, EXPERIMENTS.md R4-fold / R4-multigpu):
+    // share = blockIdx % csplit, XCD = blockIdx % 8, so with 2 / 4 splits (the slabs of a 4- / 8-GPU run) an XCD's L2 sees
+    // a half / a quarter of x, while 3 splits (6 ranks) leave every XCD all of x: 0.46 ms against 0.32 ideal.
     int want = (rb_min * 2 <= c->num_cu && A->gather_len >= 4000000) ? (int)(c->num_cu / rb_min) : 1;
     if (const char* e = getenv("HIPEIG_TCOOW_CSPLIT")) want = atoi(e);          // tuning knob (1 = off)
     if (want > 64) want = 64;

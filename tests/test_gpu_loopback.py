@@ -425,3 +425,38 @@ def test_device_group_scalars_on_loopback_ranks(hip):
         grp.close()
     for r, (gathered, mx, sm, rank, world) in enumerate(res):
         assert gathered == [0.5, 1.5, 2.5] and mx == 20.0 and sm == 6.0 and (rank, world) == (r, 3)
+
+
+def test_exchange_switch_times_one_ranks_sweeps_without_its_peers(hip):
+    """hipeig_comm_set_exchange(0) (round 4, bench.py `phases.sweeps_alone_ms`): a product places the rank's own slice and
+    skips the exchange, so ONE rank can run its launches while its peers sit idle - no collective, no wait.  With an
+    unchanged operand the gathered buffer still holds the peers' parts of the last real exchange, so the product is the
+    true one; after a changed operand it is not (the peers' parts are stale), and switching the exchange back on repairs it."""
+    N, P = 300_000, 2
+    grp = LoopbackGroup(P)
+    x = np.random.default_rng(8).standard_normal(N)
+
+    def body(rank, ctx):
+        b, e = row_range(N, P, rank)
+        H = hip.HipCsrOperator.generate(N, 32, seed=7, row_begin=b, row_end=e, ctx=ctx)
+        X = hip.HipVector(x[b:e], ctx=ctx)
+        y0 = X.applyOp(H).array                                 # a real exchange
+        out = {}
+        if rank == 1:                                            # rank 1 alone: rank 0 makes no call at all meanwhile
+            ctx.set_exchange(False)
+            out["same"] = float(np.max(np.abs(X.applyOp(H).array - y0)))
+            out["stale"] = float(np.max(np.abs((X * 2.0).applyOp(H).array - 2.0 * y0)))
+            ctx.set_exchange(True)
+        y2 = (X * 2.0).applyOp(H).array                          # collective again, both ranks
+        out["back"] = float(np.max(np.abs(y2 - 2.0 * y0)))
+        out["scale"] = float(np.max(np.abs(y0)))
+        return out
+
+    try:
+        res = grp.run(body)
+    finally:
+        grp.close()
+    assert res[1]["same"] <= 1e-13 * res[1]["scale"]
+    assert res[1]["stale"] > 1e-3 * res[1]["scale"]               # the peers' half of the operand was NOT doubled
+    for o in res:
+        assert o["back"] <= 1e-13 * o["scale"]
