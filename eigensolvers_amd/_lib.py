@@ -43,6 +43,7 @@ SIGNATURES = {
     "hipeig_direct_alloc": [_P, _I64, _P],
     "hipeig_direct_attach": [_P, _P],
     "hipeig_direct_release": [_P],
+    "hipeig_comm_set_wait_limit": [_P, C.c_double],
     "hipeig_comm_set_exchange": [_P, C.c_int],
     "hipeig_comm_set_gather_backend": [_P, C.c_int],
     "hipeig_comm_gather_info": [_P, _I64P],

@@ -414,6 +414,19 @@ int hipeig_sync_checked(hipeig_ctx* c) {
   return 0;
 }
 
+// Wall-clock limit of the wait kernels from now on (seconds; <= 0 restores the default / HIPEIG_DIRECT_WAIT_S).  A trial of
+// the backend on hardware it has never run on uses a short one so that a dead link costs seconds, not minutes.
+extern "C" int hipeig_comm_set_wait_limit(hipeig_ctx* c, double seconds) {
+  DirectComm* d = c->direct;
+  HIPEIG_REQUIRE(d != nullptr, "no direct exchange allocated");
+  if (seconds <= 0.0) {
+    seconds = DIRECT_WAIT_LIMIT_S;
+    if (const char* e = getenv("HIPEIG_DIRECT_WAIT_S")) seconds = atof(e);
+  }
+  d->wait_limit_ticks = (int64_t)(seconds * 1e8);
+  return 0;
+}
+
 // Release the buffers of the direct exchange (a collective fall-back to RCCL would otherwise keep two gathered operands
 // per rank allocated for nothing).
 extern "C" int hipeig_direct_release(hipeig_ctx* c) { return hipeig_direct_destroy(c); }

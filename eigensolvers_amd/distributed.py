@@ -355,59 +355,104 @@ def attach_direct(ctx, capacity_doubles, rank=None, world=None):
     return rank, world
 
 
-def choose_gather_backend(ctx, H, group, reps=5):
+def choose_gather_backend(ctx, H, group, reps=5, trial_wait_s=20.0):
     """Time ``reps`` products of the partitioned operator ``H`` with each exchange backend, check that they give the same
     results (to rounding: the blocked sweep adds a row's terms in no fixed order), and switch every rank to the faster
     one (max over ranks decides, so all ranks agree).  The operand CHANGES from product to product (x, 2x, 3x, ...), so a
     backend that handed the sweep a stale buffer - the previous exchange's data - would be caught, not only one that
-    delivers wrong data outright.  The direct backend must have been attached (``enable_direct_gather``).  Returns a
-    record of what was measured."""
+    delivers wrong data outright.  The direct backend must have been attached (``enable_direct_gather``).
+
+    The direct backend has never run between DIFFERENT devices (this pool has one GPU per box), so its trial is built
+    to fail safely: short wait limits (``trial_wait_s``), NO collective of any kind inside the trial - a rank whose trial
+    raises and one whose trial passes still make the same calls - and ONE host-side (TCP) all-gather of (ok, ms) behind
+    it; if any rank failed, every rank drains its device, all release the direct buffers together and the run stays on
+    RCCL.  Returns a record of what was measured."""
     import numpy as np
-    from . import _lib
     from .hip_vector import HipVector
     n = H.nrows
+    tg = tcp_group(ctx.rank, ctx.nranks)
     x = HipVector(np.random.default_rng(4242 + ctx.rank).standard_normal(n), ctx=ctx)
     xs = ctx.alloc(n)
-    ys, times = {}, {}
-    for name in ("rccl", "direct"):
+    from . import _lib
+
+    def products(name, out):
+        """warm-up, ``reps`` timed products, then 2 * reps compared ones; everything local"""
         ctx.set_gather_backend(name)
-        out = ctx.alloc(n)
         H.apply_shifted(0.0, x._buf, out)                       # warm-up (layout, buffers)
-        group.barrier()
+        ctx.synchronize()
         ctx.timer_start()
         for _ in range(reps):
             H.apply_shifted(0.0, x._buf, out)
-        times[name] = group.allmax(ctx.timer_stop() / reps)
+        ms = ctx.timer_stop() / reps
         got = []
         for i in range(2 * reps):                               # both buffers of the double-buffered exchange, several times
             _lib.call("hipeig_scale", ctx.handle, n, float(i + 1), x._buf.ptr, xs.ptr)
             H.apply_shifted(0.0, xs, out)
             got.append(HipVector(out).array / (i + 1))          # every product must equal -H x
-        ys[name] = got
-    scale = float(np.max(np.abs(ys["rccl"][0]))) if n else 0.0
-    same = ctx.gather_info()["wait_error"] == 0
-    for a, b in zip(ys["rccl"], ys["direct"]):
-        same = same and bool(np.all(np.abs(a - b) <= 1e-12 * scale)) and bool(np.all(np.abs(a - ys["rccl"][0]) <= 1e-12 * scale))
-    same = group.allmax(0.0 if same else 1.0) == 0.0
-    pick = "direct" if (same and times["direct"] < times["rccl"]) else "rccl"
+        return ms, got
+
+    out = ctx.alloc(n)
+    group.barrier()
+    ms_rccl, ref = products("rccl", out)
+    times = {"rccl": group.allmax(ms_rccl)}
+    scale = float(np.max(np.abs(ref[0]))) if n else 0.0
+    # ---- the direct trial: local only, then one host-side exchange of the verdicts ----
+    ok, why, ms_direct, ar_direct = True, "", float("inf"), float("inf")
+    try:
+        ctx.set_direct_wait_limit(trial_wait_s)
+        tg.barrier()
+        ms_direct, got = products("direct", out)
+        ok = ctx.gather_info()["wait_error"] == 0
+        for a, b in zip(ref, got):
+            ok = ok and bool(np.all(np.abs(a - b) <= 1e-12 * scale)) and bool(np.all(np.abs(a - ref[0]) <= 1e-12 * scale))
+        if not ok:
+            why = "results differ from RCCL's"
+        else:
+            # the small all-reduce of a MINRES iteration through the mailboxes: a known record ((rank + 1) * (1 .. 16),
+            # several rounds so that both mailboxes are used); its peers are exactly the ranks whose exchange just worked
+            ctx.set_allreduce_backend("direct")
+            want = np.arange(1.0, 17.0) * (ctx.nranks * (ctx.nranks + 1) / 2.0)
+            for rnd in range(4):
+                rec = HipVector((ctx.rank + 1.0) * np.arange(1.0, 17.0) * (rnd + 1), ctx=ctx)
+                ctx.allreduce_vector(rec._buf)
+                ok = ok and bool(np.array_equal(rec.array, want * (rnd + 1)))      # small integers: exact in any order
+            ar_direct = ctx.allreduce_ms(2, 50)
+            if not ok:
+                why = "all-reduce through the mailboxes gave a wrong sum"
+    except Exception as exc:                                    # noqa: BLE001 - reported, every rank falls back together
+        ok, why = False, f"{type(exc).__name__}: {exc}"
+    import json
+    try:
+        ctx.set_exchange(True)                                  # no change of state: drains BOTH streams (pushes run on the
+    except Exception:                                           # noqa: BLE001   communication stream), checks no error word
+        pass
+    verdicts = [json.loads(v.decode()) for v in tg.allgather(json.dumps([bool(ok), float(ms_direct), float(ar_direct), why]).encode())]
+    all_ok = all(v[0] for v in verdicts)
+    if not all_ok:
+        reasons = "; ".join(f"rank {r}: {v[3]}" for r, v in enumerate(verdicts) if not v[0])
+        print(f"[hipeig rank {ctx.rank}] direct exchange failed its trial ({reasons}); staying on RCCL", file=sys.stderr)
+        try:
+            ctx.direct_release()                                # clears the error word with the buffers; every rank has drained
+        except Exception:                                       # noqa: BLE001
+            pass
+        ctx.set_gather_backend("rccl")
+        ctx.set_allreduce_backend("rccl")
+        group.barrier()
+        return {"rccl_ms": round(times["rccl"], 4), "direct_ms": None, "results_agree": False, "direct_trial_failed": reasons,
+                "products_compared": 2 * reps, "chosen": "rccl", "reps": reps, "allreduce_chosen": "rccl"}
+    ctx.set_direct_wait_limit(0.0)
+    times["direct"] = max(v[1] for v in verdicts)
+    pick = "direct" if times["direct"] < times["rccl"] else "rccl"
     ctx.set_gather_backend(pick)
-    # the small all-reduce of a MINRES iteration (two doubles): same choice by the same rule, with its OWN result check -
-    # a known record ((rank + 1) * (1 .. 16), several rounds so that both mailboxes are used) summed through each backend
-    ar, ar_ok = {}, True
-    want = np.arange(1.0, 17.0) * (ctx.nranks * (ctx.nranks + 1) / 2.0)
-    for name in ("rccl", "direct"):
-        ctx.set_allreduce_backend(name)
-        for rnd in range(4):
-            rec = HipVector((ctx.rank + 1.0) * np.arange(1.0, 17.0) * (rnd + 1), ctx=ctx)
-            ctx.allreduce_vector(rec._buf)
-            ar_ok = ar_ok and bool(np.array_equal(rec.array, want * (rnd + 1)))      # small integers: exact in any order
-        ar[name] = group.allmax(ctx.allreduce_ms(2, 50))
-    ar_ok = group.allmax(0.0 if ar_ok else 1.0) == 0.0
-    pick_ar = "direct" if (same and ar_ok and ar["direct"] < ar["rccl"]) else "rccl"
+    ctx.set_allreduce_backend("rccl")
+    ar = {"rccl": group.allmax(ctx.allreduce_ms(2, 50)), "direct": max(v[2] for v in verdicts)}
+    pick_ar = "direct" if ar["direct"] < ar["rccl"] else "rccl"
     ctx.set_allreduce_backend(pick_ar)
-    return {"rccl_ms": round(times["rccl"], 4), "direct_ms": round(times["direct"], 4), "results_agree": same,
+    if pick == "rccl" and pick_ar == "rccl":
+        ctx.direct_release()                                    # nothing uses the two gathered buffers per rank: free them (all ranks decide alike)
+    return {"rccl_ms": round(times["rccl"], 4), "direct_ms": round(times["direct"], 4), "results_agree": True,
             "products_compared": 2 * reps, "chosen": pick, "reps": reps, "allreduce_rccl_ms": round(ar["rccl"], 4),
-            "allreduce_direct_ms": round(ar["direct"], 4), "allreduce_results_agree": ar_ok, "allreduce_chosen": pick_ar}
+            "allreduce_direct_ms": round(ar["direct"], 4), "allreduce_results_agree": True, "allreduce_chosen": pick_ar}
 
 
 class DeviceGroup:

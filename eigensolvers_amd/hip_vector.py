@@ -97,6 +97,10 @@ class HipContext:
         """Free the buffers of the direct exchange (after a collective fall-back to RCCL)."""
         _lib.call("hipeig_direct_release", self.handle)
 
+    def set_direct_wait_limit(self, seconds):
+        """Wall-clock limit of the direct exchange's bounded waits from now on (<= 0: the default)."""
+        _lib.call("hipeig_comm_set_wait_limit", self.handle, float(seconds))
+
     def set_exchange(self, on):
         """Measurement aid: ``False`` makes this context's products skip the operand exchange (own slice only; results
         meaningless) so that one rank's sweeps can be timed alone; switch back before the next collective product."""

@@ -82,6 +82,7 @@ int hipeig_comm_set_allreduce_backend(hipeig_ctx* ctx, int backend);  /* small a
 int hipeig_direct_alloc(hipeig_ctx* ctx, int64_t capacity_doubles, void* record192_out);
 int hipeig_direct_attach(hipeig_ctx* ctx, const void* all_records /* nranks x 192 bytes */);
 int hipeig_direct_release(hipeig_ctx* ctx);    /* frees the direct buffers again (after a collective fall-back to RCCL) */
+int hipeig_comm_set_wait_limit(hipeig_ctx* ctx, double seconds);   /* limit of the bounded waits from now on; <= 0: default */
 int hipeig_comm_set_gather_backend(hipeig_ctx* ctx, int backend);
 int hipeig_comm_gather_info(hipeig_ctx* ctx, int64_t info[8]);
 /* chunks of the operand exchange (1-4; 0 = automatic) for operators created from now on; the same on every rank */

@@ -59,6 +59,22 @@ H3 = ea.HipCsrOperator.generate(N2, 32, seed=5, ctx=ctx)          # created with
 out["choice"] = D.choose_gather_backend(ctx, H3, D.DeviceGroup(ctx), reps=3)
 out["gather_info"] = ctx.gather_info()
 ctx.set_gather_backend("rccl"); ctx.set_allreduce_backend("rccl")
+# ... and the same choice when the direct backend FAILS its trial (it has never run between different devices): an
+# injected error inside the trial - every rank falls back to RCCL together, the buffers are released, products go on
+if not ctx.gather_info()["direct_attached"]:
+    assert D.enable_direct_gather(ctx, D.gathered_capacity(N2, 1), 0, 1)
+orig = ctx.set_gather_backend
+def failing(name):
+    if name == "direct":
+        raise RuntimeError("injected failure of the direct trial")
+    return orig(name)
+ctx.set_gather_backend = failing
+out["failed_choice"] = D.choose_gather_backend(ctx, H3, D.DeviceGroup(ctx), reps=2)
+ctx.set_gather_backend = orig
+out["gather_info_after_failure"] = ctx.gather_info()
+y_after = x2.applyOp(H3)
+d = ea.HipVector.linearCombination([y_after, y_ref], [1.0, -1.0])
+out["product_after_failure_rel"] = d.norm() / y_ref.norm()
 import ctypes
 buf = ctypes.create_string_buffer(512)
 ea._lib.call("hipeig_comm_library", buf, 512)
@@ -87,6 +103,12 @@ def test_forced_collectives_single_rank():
     ch = r["choice"]
     assert ch["results_agree"] and ch["products_compared"] == 6 and ch["chosen"] in ("rccl", "direct")
     assert ch["rccl_ms"] > 0 and ch["direct_ms"] > 0 and ch["allreduce_rccl_ms"] > 0 and ch["allreduce_direct_ms"] > 0
-    assert r["gather_info"]["direct_attached"] and r["gather_info"]["wait_error"] == 0
+    assert ch["allreduce_results_agree"] and r["gather_info"]["wait_error"] == 0
+    # the two gathered buffers per rank stay only if one of the two direct backends won
+    assert r["gather_info"]["direct_attached"] == ("direct" in (ch["chosen"], ch["allreduce_chosen"]))
+    fc = r["failed_choice"]
+    assert fc["chosen"] == "rccl" and fc["allreduce_chosen"] == "rccl" and "injected failure" in fc["direct_trial_failed"]
+    assert not r["gather_info_after_failure"]["direct_attached"] and r["gather_info_after_failure"]["backend"] == "rccl"
+    assert r["product_after_failure_rel"] < 1e-14
     # the collectives run on ROCm's own RCCL, whatever else the process has loaded; no torch on the product path
     assert r["rccl"].startswith("/opt/rocm") and not r["torch_loaded"], r["rccl"]
