@@ -398,9 +398,9 @@ def choose_gather_backend(ctx, H, group, reps=5, trial_wait_s=20.0):
     scale = float(np.max(np.abs(ref[0]))) if n else 0.0
     # ---- the direct trial: local only, then one host-side exchange of the verdicts ----
     ok, why, ms_direct, ar_direct = True, "", float("inf"), float("inf")
+    tg.barrier()                                                # every rank is past the RCCL part (outside the try: every rank makes it)
     try:
         ctx.set_direct_wait_limit(trial_wait_s)
-        tg.barrier()
         ms_direct, got = products("direct", out)
         ok = ctx.gather_info()["wait_error"] == 0
         for a, b in zip(ref, got):
