@@ -365,9 +365,11 @@ extern "C" int hipeig_spmm_shift_pairs(hipeig_ctx* c, hipeig_csr* A, int npairs,
   const int64_t nx = A->ncols, ny = A->nrows;
   // complex operands per pass over the operator: 4 (an 8-wide block, 64 B per operand row: a gather uses half a line) or 8
   // (16 wide, 128 B = one whole line per gather; HIPEIG_PAIR_BLOCK_WIDTH, see EXPERIMENTS.md R4-block16)
-  // Measured per complex operand: N = 1e6 0.107 (4 per pass) / 0.109 (8); N = 1e7 2.98 / 1.85 ms (single pair products:
-  // 0.177 / 3.94) - 8 per pass once the 16-wide operand block (128 B per row) no longer sits in the caches.
-  int wide = (nx * (int64_t)128 > ((int64_t)192 << 20)) ? 8 : 4;
+  // Measured per complex operand, 4 / 8 per pass (tools/experiments/pair_block_width.py): N = 1e6 0.107 / 0.109, 2e6 0.387 /
+  // 0.365, 4e6 0.933 / 0.973, 1e7 2.98 / 1.85 ms (single pair products: 0.177 / 0.51 / 1.46 / 3.94).  Within +-6 % while the
+  // 8-wide block (64 B per row) still sits in the 256 MiB Infinity Cache; once it does not, its gathers pay a whole line from
+  // HBM for half a line of data and the 16-wide block wins by 38 %.
+  int wide = (nx * (int64_t)64 > ((int64_t)288 << 20)) ? 8 : 4;
   if (const char* e = getenv("HIPEIG_PAIR_BLOCK_WIDTH")) wide = atoi(e) >= 8 ? 8 : 4;
   if (ensure_blk_ws(c, (size_t)(nx + ny) * BCOO_KPACK)) return 1;
   double* Xi = c->blk_ws;
