@@ -608,6 +608,9 @@ def test_batched_arnoldi_steps_equal_the_single_steps(hip, n):
     step at these lengths, so coefficients, norms and the normalised vectors are bit-identical; a longer vector is
     declined (the caller then enqueues the steps one by one)."""
     from eigensolvers_amd.gcrotmk import _PairOps
+    import os
+    if os.environ.get("HIPEIG_MAPPED_SCALARS") == "0":
+        pytest.skip("the batched form needs the mapped scalar area (it is declined without it: status 5)")
     ctx = hip.HipContext.default()
     rng = np.random.default_rng(n)
     counts = [0, 1, 7, 40, 62, 3]
