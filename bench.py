@@ -154,10 +154,13 @@ def main(result):
                 "why": "HIPEIG_COMM=" + comm_mode if comm_mode != "auto" else "direct exchange unavailable (see stderr)"}
 
     exchange = None
-    if world > 1 and os.environ.get("HIPEIG_BENCH_CHUNK_TRIALS", "0") not in ("", "0") and "HIPEIG_GATHER_CHUNKS" not in os.environ:
-        # Experiment mode (off by default: it doubles the start-up of every rank): build the operator with one and with
-        # two exchange chunks, let each pick its exchange backend, time 10 products, keep the faster.  Only the timings
-        # of the losing build are kept, not the build.
+    if world > 1 and os.environ.get("HIPEIG_BENCH_CHUNK_TRIALS", "1") not in ("", "0") and "HIPEIG_GATHER_CHUNKS" not in os.environ:
+        # How many chunks the operand exchange is cut into decides between fewer launches / slabs (one chunk: a rank's
+        # sweeps alone 0.30-0.34 ms at 8 ranks) and more overlap (two: 0.33-0.35 ms, but the first half of the remote
+        # windows starts when half the exchange is through) - which wins depends on the exchange time of the machine, so it
+        # is measured: build the operator with one and with two chunks (~1 s each), let each pick its exchange backend, time
+        # 10 products, keep the faster and rebuild it.  Only the timings of the trials are kept, never two operators at once.
+        # HIPEIG_BENCH_CHUNK_TRIALS=0 takes the library's layout rule instead (one build).
         tried = {}
         for nch in (1, 2):
             ctx.set_gather_chunks(nch)
