@@ -1435,8 +1435,46 @@ arnoldi_block_kernel(int64_t n, const double* __restrict__ tin, int nb_in, ArnBl
   }
 }
 
+// Workspace of one blocked Arnoldi step: a stream and what the step keeps per stream (so that the steps of different
+// right-hand sides can run on different streams at once).
+struct ArnSpace {
+  hipStream_t stream;
+  double* partials;          // Sh::NV areas of <= 8192 doubles
+  double* tot;               // two total records of 32 doubles, used alternately
+  unsigned* cnt;             // ticket counters (zero between kernels)
+};
+
+static ArnSpace arnoldi_main_space(hipeig_ctx* c) {
+  return ArnSpace{c->stream, c->d_partials, c->d_scalars + 3200, c->d_counters + 3 * HIPEIG_TICKET_WORDS};
+}
+
+#define ARN_SIDE_PARTIALS (32 * 8192)      // doubles per side stream: >= Sh::NV (21) areas of 8192
+#define ARN_SIDE_DOUBLES (ARN_SIDE_PARTIALS + 64 + 128)      // + two total records + the step's result record
+
+// The side streams are created on first use: HIPEIG_ARNOLDI_STREAMS of them (1..4; 1 = none, everything on the compute stream).
+// Measured (tools/experiments/gcrot_block_solve.py, the 16 solves of one contour point, 4-column sweeps): 1 / 2 / 4 streams
+// at N = 1e6 8.78 / 8.70 / 7.16 s, at N = 4e6 22.8 / - / 21.9 s, at N = 1e7 37.9 / - / 36.3 s - a sweep of 160 MB does not fill
+// the chip at N = 1e6 (4.3 TB/s: launch ramp, the ticket tail), four of them from four right-hand sides do; identical
+// coefficients and iteration counts.  Config #5 at N = 1e6 to convergence: 245 -> 200 s.
+static int arnoldi_side_streams(hipeig_ctx* c) {
+  if (c->arn_nstreams) return 0;
+  int ns = 4;
+  if (const char* e = getenv("HIPEIG_ARNOLDI_STREAMS")) ns = atoi(e);
+  if (ns < 1) ns = 1;
+  if (ns > 4) ns = 4;
+  if (ns > 1) {
+    HIPEIG_CHECK(hipMalloc((void**)&c->d_arn_ws, (size_t)ns * ARN_SIDE_DOUBLES * sizeof(double)));
+    HIPEIG_CHECK(hipMalloc((void**)&c->d_arn_cnt, (size_t)ns * HIPEIG_TICKET_WORDS * sizeof(unsigned)));
+    HIPEIG_CHECK(hipMemset(c->d_arn_cnt, 0, (size_t)ns * HIPEIG_TICKET_WORDS * sizeof(unsigned)));
+    for (int k = 0; k < ns; ++k) HIPEIG_CHECK(hipStreamCreateWithFlags(&c->arn_stream[k], hipStreamNonBlocking));
+    for (int k = 0; k < 16; ++k) HIPEIG_CHECK(hipEventCreateWithFlags(&c->ev_arn_in[k], hipEventDisableTiming));
+  }
+  c->arn_nstreams = ns;
+  return 0;
+}
+
 template <bool PAIR>
-static int arnoldi_blocked(hipeig_ctx* c, int64_t n, int m, const double* const* Vre, const double* const* Vim,
+static int arnoldi_blocked(hipeig_ctx* c, const ArnSpace& sp, int64_t n, int m, const double* const* Vre, const double* const* Vim,
                            double* wre, double* wim, double* dres) {
   using Sh = ArnBlockShape<PAIR>;
   constexpr int W = Sh::W;
@@ -1450,9 +1488,9 @@ static int arnoldi_blocked(hipeig_ctx* c, int64_t n, int m, const double* const*
   if ((int64_t)g * ARN_BLOCK_THREADS * 2 > n) g = (int)((n / 2 + ARN_BLOCK_THREADS - 1) / ARN_BLOCK_THREADS);
   if (g < 1) g = 1;
   if (g > 8192) g = 8192;                                      // Sh::NV partial areas of g doubles each
-  double* P0 = c->d_partials;
-  double* tot = c->d_scalars + 3200;                           // two total records of <= 32 doubles, used alternately
-  unsigned* cnt = c->d_counters + 3 * HIPEIG_TICKET_WORDS;
+  double* P0 = sp.partials;
+  double* tot = sp.tot;                                        // two total records of <= 32 doubles, used alternately
+  unsigned* cnt = sp.cnt;
   auto cols = [&](int b0, ArnBlockCols* out) -> int {
     int nb = m - b0;
     if (nb > ARN_P) nb = ARN_P;
@@ -1467,7 +1505,7 @@ static int arnoldi_blocked(hipeig_ctx* c, int64_t n, int m, const double* const*
   cols(m, &none);
   int nb_next = cols(0, &nxt);
   // first pass: ||w||^2 before and everything block 0 needs (no update); with m == 0 it is also ||w||^2 after
-  hipLaunchKernelGGL((arnoldi_block_kernel<PAIR>), dim3(g), dim3(ARN_BLOCK_THREADS), 0, c->stream, n, (const double*)nullptr, 0, none,
+  hipLaunchKernelGGL((arnoldi_block_kernel<PAIR>), dim3(g), dim3(ARN_BLOCK_THREADS), 0, sp.stream, n, (const double*)nullptr, 0, none,
                      nb_next, nxt, 1, wre, wim, (double*)nullptr, P0, cnt, tot, dres);
   int flip = 0;
   for (int b0 = 0; b0 < m; b0 += ARN_P) {
@@ -1475,14 +1513,14 @@ static int arnoldi_blocked(hipeig_ctx* c, int64_t n, int m, const double* const*
     const int nb_in = nb_next;
     nb_next = cols(b0 + ARN_P, &nxt);
     const int last = (nb_next == 0);
-    hipLaunchKernelGGL((arnoldi_block_kernel<PAIR>), dim3(g), dim3(ARN_BLOCK_THREADS), 0, c->stream, n, tot + 32 * flip, nb_in, cur,
+    hipLaunchKernelGGL((arnoldi_block_kernel<PAIR>), dim3(g), dim3(ARN_BLOCK_THREADS), 0, sp.stream, n, tot + 32 * flip, nb_in, cur,
                        nb_next, nxt, last, wre, wim, dres + 1 + W * b0, P0, cnt, tot + 32 * (flip ^ 1),
                        last ? dres + 1 + W * m : (double*)nullptr);
     flip ^= 1;
   }
   if (m == 0)
-    HIPEIG_CHECK(hipMemcpyAsync(dres + 1, dres, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  hipLaunchKernelGGL(scale_by_inv_norm_kernel, dim3(grid_stream(n)), dim3(HIPEIG_BLOCK), 0, c->stream, n, dres + 1 + W * m, wre, wim);
+    HIPEIG_CHECK(hipMemcpyAsync(dres + 1, dres, sizeof(double), hipMemcpyDeviceToDevice, sp.stream));
+  hipLaunchKernelGGL(scale_by_inv_norm_kernel, dim3(grid_stream(n)), dim3(HIPEIG_BLOCK), 0, sp.stream, n, dres + 1 + W * m, wre, wim);
   HIPEIG_CHECK(hipGetLastError());
   return 0;
 }
@@ -1572,7 +1610,7 @@ extern "C" int hipeig_arnoldi_step_p(hipeig_ctx* c, int64_t n, int m, const doub
   if (cols_per_pass == 1 || c->collectives || n <= (int64_t)ARN_SMALL_THREADS * ARN_SMALL_E) return hipeig_arnoldi_step(c, n, m, V, w, out);
   HIPEIG_REQUIRE(m >= 0 && m <= 600 && out, "bad arguments");
   double* dres = c->d_scalars + 2560;                  // m + 2 doubles (< 640: the total records sit at 3200)
-  if (arnoldi_blocked<false>(c, n, m, V, nullptr, w, nullptr, dres)) return 4;
+  if (arnoldi_blocked<false>(c, arnoldi_main_space(c), n, m, V, nullptr, w, nullptr, dres)) return 4;
   HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dres, sizeof(double) * (m + 2), hipMemcpyDeviceToHost, c->stream));
   if (hipeig_sync_checked(c)) return 4;
   memcpy(out, c->h_scalars, sizeof(double) * (m + 2));
@@ -1586,7 +1624,7 @@ extern "C" int hipeig_pair_arnoldi_step_p(hipeig_ctx* c, int64_t n, int m, const
     return hipeig_pair_arnoldi_step(c, n, m, Vre, Vim, wre, wim, out);
   HIPEIG_REQUIRE(m >= 0 && m <= 250 && out, "bad arguments");
   double* dres = c->d_scalars + 2560;                  // 2m + 2 doubles (< 640: the total records sit at 3200)
-  if (arnoldi_blocked<true>(c, n, m, Vre, Vim, wre, wim, dres)) return 4;
+  if (arnoldi_blocked<true>(c, arnoldi_main_space(c), n, m, Vre, Vim, wre, wim, dres)) return 4;
   HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars, dres, sizeof(double) * (2 * m + 2), hipMemcpyDeviceToHost, c->stream));
   if (hipeig_sync_checked(c)) return 4;
   memcpy(out, c->h_scalars, sizeof(double) * (2 * m + 2));
@@ -1606,7 +1644,27 @@ extern "C" int hipeig_pair_arnoldi_step_begin(hipeig_ctx* c, int64_t n, int m, c
   const bool blocked = cols_per_pass != 1 && n > (int64_t)ARN_SMALL_THREADS * ARN_SMALL_E;
   const bool direct = !blocked && c->h_scalars_dev && arnoldi_is_small(n, m);
   if (direct) dres = c->h_scalars_dev + 2048 + (size_t)slot * ARN_SLOT_DOUBLES;
-  if (blocked ? arnoldi_blocked<true>(c, n, m, Vre, Vim, wre, wim, dres) : arnoldi_fused<true>(c, n, m, Vre, Vim, wre, wim, dres)) return 4;
+  if (blocked) {
+    if (arnoldi_side_streams(c)) return 4;
+    if (c->arn_nstreams > 1) {
+      // The steps of the right-hand sides are independent: slot s runs on side stream s % ns with that stream's own partial
+      // areas, total records, ticket counters and result record, behind an event that says "the compute stream has produced
+      // this slot's operands".  The caller collects the slot (hipeig_arnoldi_step_end waits for the slot's event) before it
+      // enqueues anything that reads what the step wrote, so nothing on the compute stream has to wait for the side stream.
+      const int k = slot % c->arn_nstreams;
+      double* base = c->d_arn_ws + (size_t)k * ARN_SIDE_DOUBLES;
+      const ArnSpace sp{c->arn_stream[k], base, base + ARN_SIDE_PARTIALS, c->d_arn_cnt + (size_t)k * HIPEIG_TICKET_WORDS};
+      double* res = base + ARN_SIDE_PARTIALS + 64;
+      HIPEIG_CHECK(hipEventRecord(c->ev_arn_in[slot], c->stream));
+      HIPEIG_CHECK(hipStreamWaitEvent(sp.stream, c->ev_arn_in[slot], 0));
+      if (arnoldi_blocked<true>(c, sp, n, m, Vre, Vim, wre, wim, res)) return 4;
+      HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars + 2048 + (size_t)slot * ARN_SLOT_DOUBLES, res, sizeof(double) * (2 * m + 2),
+                                  hipMemcpyDeviceToHost, sp.stream));
+      HIPEIG_CHECK(hipEventRecord(c->ev_slot[slot], sp.stream));
+      return 0;
+    }
+  }
+  if (blocked ? arnoldi_blocked<true>(c, arnoldi_main_space(c), n, m, Vre, Vim, wre, wim, dres) : arnoldi_fused<true>(c, n, m, Vre, Vim, wre, wim, dres)) return 4;
   if (!direct)
     HIPEIG_CHECK(hipMemcpyAsync(c->h_scalars + 2048 + (size_t)slot * ARN_SLOT_DOUBLES, dres, sizeof(double) * (2 * m + 2),
                                 hipMemcpyDeviceToHost, c->stream));

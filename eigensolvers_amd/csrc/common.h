@@ -125,6 +125,13 @@ struct hipeig_ctx {
   hipEvent_t ev_ph[8];
   hipEvent_t ev_stage;       // behind the last asynchronous copy out of the pinned staging buffers (hipeig_lincomb_block)
   hipEvent_t ev_slot[16];    // one per pinned result slot of the split Arnoldi step (hipeig_pair_arnoldi_step_begin)
+  // side streams of the split Arnoldi step (hipeig_pair_arnoldi_step_begin): the steps of the right-hand sides of a lock-step
+  // block solve are independent, so slot s runs on side stream s % arn_nstreams with that stream's own workspace
+  hipStream_t arn_stream[4];
+  hipEvent_t ev_arn_in[16];  // "the compute stream has produced this slot's operands"
+  int arn_nstreams;          // 0: not created yet; 1: everything on the compute stream
+  double* d_arn_ws;          // per side stream: partial areas, two total records, the step's result record
+  unsigned* d_arn_cnt;       // per side stream: ticket counters
   void* h_arn_items;         // pinned, mapped: the items of a batched Arnoldi step (hipeig_pair_arnoldi_step_batch_begin)
   void* d_arn_items;         // the same as the device sees it
   // direct all-gather backend (comm_direct.hip): peers' operand buffers and flags mapped through hipIpc

@@ -11,9 +11,12 @@ ctx = ea.HipContext.default()
 rng = np.random.default_rng(0)
 V = [(ea.HipVector(rng.standard_normal(N) / np.sqrt(2 * N))._buf, ea.HipVector(rng.standard_normal(N) / np.sqrt(2 * N))._buf) for _ in range(m)]
 w0 = (rng.standard_normal(N), rng.standard_normal(N))
-for cols in (1, 4, 1, 4):
+t_go = float(os.environ.get("ARN_START_AT", "0"))      # concurrent copies: all start their timed loops at this wall-clock time
+for cols in ((4,) if t_go else (1, 4, 1, 4)):
     ops = _PairOps(ctx, N, cols)
     ts = []
+    while time.time() < t_go:
+        time.sleep(0.001)
     for r in range(reps):
         w = (ea.HipVector(w0[0].copy())._buf, ea.HipVector(w0[1].copy())._buf)
         ctx.synchronize()
