@@ -1451,17 +1451,17 @@ static ArnSpace arnoldi_main_space(hipeig_ctx* c) {
 #define ARN_SIDE_PARTIALS (32 * 8192)      // doubles per side stream: >= Sh::NV (21) areas of 8192
 #define ARN_SIDE_DOUBLES (ARN_SIDE_PARTIALS + 64 + 128)      // + two total records + the step's result record
 
-// The side streams are created on first use: HIPEIG_ARNOLDI_STREAMS of them (1..4; 1 = none, everything on the compute stream).
-// Measured (tools/experiments/gcrot_block_solve.py, the 16 solves of one contour point, 4-column sweeps): 1 / 2 / 4 streams
-// at N = 1e6 8.78 / 8.70 / 7.16 s, at N = 4e6 22.8 / - / 21.9 s, at N = 1e7 37.9 / - / 36.3 s - a sweep of 160 MB does not fill
-// the chip at N = 1e6 (4.3 TB/s: launch ramp, the ticket tail), four of them from four right-hand sides do; identical
-// coefficients and iteration counts.  Config #5 at N = 1e6 to convergence: 245 -> 200 s.
+// The side streams are created on first use: HIPEIG_ARNOLDI_STREAMS of them (1..16; 1 = none, everything on the compute stream).
+// Measured (tools/experiments/gcrot_block_solve.py, the 16 solves of one contour point, 4-column sweeps): 1 / 2 / 4 / 8 / 16
+// streams at N = 1e6 8.78 / 8.70 / 7.13 / 6.70 / 6.64 s (6: 7.26; with GPU_MAX_HW_QUEUES=8 instead of the runtime's 4: 7.1-7.3),
+// at N = 4e6 22.8 / - / 21.9 s, at N = 1e7 37.9 / - / 36.3 / 36.2 s - a sweep of 160 MB does not fill the chip at N = 1e6 (4.3 TB/s:
+// launch ramp, the ticket tail), several of them from different right-hand sides do; identical coefficients and iteration counts.
 static int arnoldi_side_streams(hipeig_ctx* c) {
   if (c->arn_nstreams) return 0;
-  int ns = 4;
+  int ns = 8;
   if (const char* e = getenv("HIPEIG_ARNOLDI_STREAMS")) ns = atoi(e);
   if (ns < 1) ns = 1;
-  if (ns > 4) ns = 4;
+  if (ns > 16) ns = 16;
   if (ns > 1) {
     HIPEIG_CHECK(hipMalloc((void**)&c->d_arn_ws, (size_t)ns * ARN_SIDE_DOUBLES * sizeof(double)));
     HIPEIG_CHECK(hipMalloc((void**)&c->d_arn_cnt, (size_t)ns * HIPEIG_TICKET_WORDS * sizeof(unsigned)));

@@ -127,7 +127,7 @@ struct hipeig_ctx {
   hipEvent_t ev_slot[16];    // one per pinned result slot of the split Arnoldi step (hipeig_pair_arnoldi_step_begin)
   // side streams of the split Arnoldi step (hipeig_pair_arnoldi_step_begin): the steps of the right-hand sides of a lock-step
   // block solve are independent, so slot s runs on side stream s % arn_nstreams with that stream's own workspace
-  hipStream_t arn_stream[4];
+  hipStream_t arn_stream[16];
   hipEvent_t ev_arn_in[16];  // "the compute stream has produced this slot's operands"
   int arn_nstreams;          // 0: not created yet; 1: everything on the compute stream
   double* d_arn_ws;          // per side stream: partial areas, two total records, the step's result record

@@ -77,7 +77,7 @@ extern "C" int hipeig_ctx_destroy(hipeig_ctx* c) {
   hipFree(c->d_scalars);
   hipHostFree(c->h_scalars);
   if (c->h_arn_items) hipHostFree(c->h_arn_items);
-  for (int k = 0; k < 4; ++k) if (c->arn_stream[k]) { hipStreamSynchronize(c->arn_stream[k]); hipStreamDestroy(c->arn_stream[k]); }
+  for (int k = 0; k < 16; ++k) if (c->arn_stream[k]) { hipStreamSynchronize(c->arn_stream[k]); hipStreamDestroy(c->arn_stream[k]); }
   for (int k = 0; k < 16; ++k) if (c->ev_arn_in[k]) hipEventDestroy(c->ev_arn_in[k]);
   if (c->d_arn_ws) hipFree(c->d_arn_ws);
   if (c->d_arn_cnt) hipFree(c->d_arn_cnt);
@@ -113,7 +113,7 @@ extern "C" int hipeig_ctx_destroy(hipeig_ctx* c) {
 }
 
 extern "C" int hipeig_ctx_sync(hipeig_ctx* c) {
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 16; ++k)
     if (c->arn_stream[k]) HIPEIG_CHECK(hipStreamSynchronize(c->arn_stream[k]));
   if (hipeig_sync_checked(c)) return 4;
   return 0;
